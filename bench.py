@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the TERSE/PROLIX hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch: Terse-encode the resident 2000-frame
+512x512 uint16 synth-v1 stack (BASELINE.json configs[1]), gather the per-frame sizes across ranks
+(RCCL, N>1 only), Prolix-decode it again (configs[2]).  Inputs are resident in HBM before the timed
+region; nothing is cached between steps (outputs are re-produced every step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the launch stream) and `cpu_baseline` (the reference's CPU path, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+N_VALUES = 512 * 512
+FRAMES_PER_GPU = 2000
+ENC_STAGES = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
+DEC_STAGES = ["walk", "unpack"]
+
+
+def cpu_baseline(px_host: np.ndarray, cores: int):
+    """The reference's CPU path timed on this box's host cores (bounded sample)."""
+    from oracle import oracle as O
+    frames = px_host.shape[0]
+    kind = "reference" if O.have_ref() else "port"
+    chunks = [px_host[i::cores] for i in range(cores)]
+    chunks = [np.ascontiguousarray(c) for c in chunks if c.shape[0]]
+
+    def run(c):
+        return O.time_ref(c) if kind == "reference" else O.time_port(c, 1)
+
+    one = run(np.ascontiguousarray(px_host[:64]))                       # 1-thread rate (and warm-up)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(chunks)) as ex:
+        res = list(ex.map(run, chunks))
+    wall = time.perf_counter() - t0
+    assert all(r["ok"] for r in res) and one["ok"], "CPU baseline failed to round-trip"
+    enc_wall = max(r["enc_s"] for r in res)
+    dec_wall = max(r["dec_s"] for r in res)
+    return {
+        "value": frames / (enc_wall + dec_wall), "unit": "frames/s", "cores": len(chunks), "kind": kind,
+        "sample": f"{frames} frames 512x512 u16 synth-v1, encode+decode, one codec object per frame, "
+                  f"{len(chunks)} threads (frames strided), wall {wall:.2f}s",
+        "encode_fps": frames / enc_wall, "decode_fps": frames / dec_wall,
+        "one_thread_encode_fps": 64 / one["enc_s"], "one_thread_decode_fps": 64 / one["dec_s"],
+        "compressed_bytes": int(sum(r["bytes"] for r in res)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default: configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from trpx_amd import codec, sharded, _lib
+    L = _lib.lib()
+
+    frames = args.frames
+    frame0 = rank * frames                                   # C5: GPU g <- frames [2000g, 2000g+2000)
+    px = codec.synth(np.uint16, frame0, frames, N_VALUES, device=dev)
+    ws = codec.Workspace(dev)
+    cap = (frames * codec.worst_case_bytes(np.uint16, N_VALUES) + 15) // 16 * 16
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offs = torch.empty(frames + 1, dtype=torch.int64, device=dev)
+    st_e = torch.empty(8, dtype=torch.int32, device=dev)
+    st_d = torch.empty(8, dtype=torch.int32, device=dev)
+    back = torch.empty((frames, N_VALUES), dtype=torch.uint16, device=dev)
+    # size the workspace once (never allocate inside the timed region)
+    ws.get(max(L.trpx_encode_workspace_bytes(_lib.U16, N_VALUES, frames, 12),
+               L.trpx_decode_workspace_bytes(_lib.U16, N_VALUES, frames, 12)))
+    torch.cuda.synchronize()
+
+    def step():
+        enc = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
+        if world > 1:   # per-frame size gather over xGMI -> global byte offsets of every frame
+            sharded.gather_global_offsets(offs, st_e[1:2])
+        # decode straight from the device-resident stack (bounded by its worst-case capacity; the
+        # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
+        codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+        return enc
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was just timed (every rank) -----------------------------------
+    assert int(st_e[0].item()) == 0 and int(st_d[0].item()) == 0, "device status reports an error"
+    assert torch.equal(back.view(torch.int16), px.view(torch.int16)), "round trip is not pixel-identical"
+    total_bytes = int(offs[-1].item())
+    if rank == 0 and frames == FRAMES_PER_GPU:
+        assert total_bytes == 203596114, "stack size differs from the reference's (SURVEY.md 8 row d)"
+
+    # ---- separate encode-only / decode-only rates + per-kernel HIP-event timing (rank 0) ----
+    detail = {}
+    if rank == 0:
+        reps = max(5, min(args.steps, 20))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
+        ev[1].record()
+        for _ in range(reps):
+            codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+        ev[2].record()
+        torch.cuda.synchronize()
+        enc_ms = ev[0].elapsed_time(ev[1]) / reps
+        dec_ms = ev[1].elapsed_time(ev[2]) / reps
+        # per-kernel durations: HIP events recorded by the library on the launch stream
+        L.trpx_profile_enable(1)
+        stage = {n: [] for n in ENC_STAGES + DEC_STAGES}
+        buf = (C.c_float * 8)()
+        for _ in range(reps):
+            codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
+            n = L.trpx_profile_read(buf, 8)
+            for k in range(n):
+                stage[ENC_STAGES[k]].append(buf[k])
+            codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+            n = L.trpx_profile_read(buf, 8)
+            for k in range(n):
+                stage[DEC_STAGES[k]].append(buf[k])
+        L.trpx_profile_enable(0)
+        stage_ms = {k: float(np.mean(v)) for k, v in stage.items() if v}
+        pix_bytes = frames * N_VALUES * 2
+        detail = {
+            "encode_ms": enc_ms, "decode_ms": dec_ms,
+            "encode_fps": frames / enc_ms * 1e3, "decode_fps": frames / dec_ms * 1e3,
+            "encode_pixel_GBps": pix_bytes / enc_ms / 1e6, "decode_pixel_GBps": pix_bytes / dec_ms / 1e6,
+            "encode_algorithmic_GBps": (pix_bytes + total_bytes) / enc_ms / 1e6,
+            "decode_algorithmic_GBps": (pix_bytes + total_bytes) / dec_ms / 1e6,
+            "encode_pixel_frac_of_hbm_peak": pix_bytes / enc_ms / 1e6 / HBM_PEAK_GBPS,
+            "decode_pixel_frac_of_hbm_peak": pix_bytes / dec_ms / 1e6 / HBM_PEAK_GBPS,
+            "kernel_ms": stage_ms, "compressed_bytes_per_gpu": total_bytes,
+            "compression_ratio": total_bytes / pix_bytes,
+        }
+        # dominant kernel = k_pack: reads every pixel once, writes every stream byte once
+        pack_ms = stage_ms.get("pack")
+        alg_bytes = pix_bytes + total_bytes                    # B_enc = N*sizeof(T) + S_f per frame
+        roofline = {"bound": "hbm", "kernel": "k_pack<uint16_t>", "achieved": alg_bytes / pack_ms / 1e6,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / pack_ms / 1e6 / HBM_PEAK_GBPS,
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pack_ms}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": "frames/s (Terse encode + Prolix decode round trip, 512x512 uint16 stack, bit-exact vs CPU ref)",
+            "value": world * frames * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
+            "data": "synthetic (synth-v1 counter-based frames, SURVEY.md 8 row d)",
+            "config": {"workload": f"{frames}-frame 512x512 uint16 synth-v1 stack per GPU: Terse encode "
+                                   f"(configs[1]) + Prolix decode (configs[2])",
+                       "frames_per_gpu": frames, "n_values": N_VALUES, "block": 12,
+                       "parallelism": f"frames sharded {world}-way, RCCL all-gather of per-frame sizes"},
+            "roundtrip_GBps_pixels": world * frames * N_VALUES * 2 * 2 * args.steps / elapsed / 1e9,
+            "roofline": roofline,
+        }
+        result.update(detail)
+        if world == 1 and not args.no_cpu_baseline:
+            cores = len(os.sched_getaffinity(0))
+            result["cpu_baseline"] = cpu_baseline(px.cpu().numpy(), cores)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * trpx_hip.h -- C ABI of libtrpx_hip.so: the MI355X (gfx950) implementation of the
+ * TERSE encode / PROLIX decode hot path of senikm/trpx.
+ *
+ * The reference has no FFI/plugin boundary: the hot path is the two inline bodies
+ * jpa::Terse::f_compress (include/Terse.hpp:500-549) and jpa::Terse::prolix(Iterator, frame)
+ * (include/Terse.hpp:352-389) plus the Bit_pointer.hpp primitives they use.  This header is
+ * the boundary a maintainer would bind instead (INTEGRATION.md shows the binding).  Plain
+ * pointers and sizes only, no C++/torch types, no exceptions across the boundary.
+ *
+ * Conventions
+ *   - every function returning int returns TRPX_OK (0) or a trpx_status error code;
+ *     trpx_last_error_string() gives the thread's last error text.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - functions taking DEVICE pointers only enqueue work on `stream`: no allocation, no
+ *     host synchronisation (they can be captured into a hipGraph); the caller supplies the
+ *     workspace.  The *_host convenience entry points own their staging and synchronise.
+ *   - the bitstream is bit-identical to the reference's: a stack is the
+ *     plain concatenation of its frames, frame k starting at byte frame_offsets[k]
+ *     (Terse.hpp:502-504; the intended semantics of Terse.hpp:562-585).
+ */
+#ifndef TRPX_HIP_H
+#define TRPX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRPX_ABI_VERSION 1
+
+typedef enum trpx_status {
+    TRPX_OK = 0,
+    TRPX_ERR_INVALID_ARG = 1,   /* null/misaligned pointer, zero sizes, unknown dtype        */
+    TRPX_ERR_UNSUPPORTED = 2,   /* e.g. block != 12 on the tuned GPU path, 64-bit pixels      */
+    TRPX_ERR_CAPACITY = 3,      /* output or workspace too small                              */
+    TRPX_ERR_HIP = 4,           /* a HIP runtime call failed (text has the HIP error)         */
+    TRPX_ERR_CORRUPT = 5,       /* bitstream runs past its frame / buffer                     */
+    TRPX_ERR_NO_DEVICE = 6      /* no gfx950 device visible                                   */
+} trpx_status;
+
+/* Pixel types = the reference CLI's dispatch set (src/terse.cpp:113-118). Odd = signed. */
+typedef enum trpx_dtype {
+    TRPX_U8 = 0, TRPX_I8 = 1, TRPX_U16 = 2, TRPX_I16 = 3, TRPX_U32 = 4, TRPX_I32 = 5
+} trpx_dtype;
+
+/* Device status block written by the kernels (u32 words); zeroed by each call's first node. */
+enum { TRPX_STATUS_WORDS = 8 };
+/*   word 0: 0 = ok, else a trpx_status (CAPACITY / CORRUPT) detected on the device
+ *   word 1: prolix_bits of this call (max significant bits over all blocks, Terse.hpp:516)   */
+
+int         trpx_abi_version(void);
+const char* trpx_last_error_string(void);
+size_t      trpx_dtype_size(int dtype);          /* 0 for an unknown dtype */
+int         trpx_dtype_is_signed(int dtype);
+int         trpx_device_count(void);             /* gfx950 devices visible to HIP; 0 = none   */
+
+/*
+ * Bytes that can hold ANY encoding of one frame: N*sizeof(T) + ceil(12*nblocks/8) + 1.
+ * Replaces the (slightly short) bound of Terse.hpp:503.  Pure arithmetic.
+ */
+size_t trpx_worst_case_bytes(int dtype, size_t n_values, unsigned block);
+
+/* Workspace sizes (bytes) for the device entry points below.  Pure arithmetic. */
+size_t trpx_encode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
+size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
+
+/*
+ * Encode n_frames frames of n_values pixels each (contiguous, frame-major, DEVICE memory) into
+ * one compact stack.  Replaces jpa::Terse::f_compress called once per frame from the ctor /
+ * push_back (Terse.hpp:263-270, :290-302, :500-549) and the Bit_range::append_range /
+ * operator|= / Bit::set primitives under it (Bit_pointer.hpp:700-730, :628-649, :490).
+ *
+ *   pixels        DEVICE  const T[n_frames * n_values], 16-byte aligned
+ *   out           DEVICE  uint8_t[out_capacity], 16-byte aligned; receives sum(S_f) bytes
+ *   frame_offsets DEVICE  uint64_t[n_frames + 1]; [k] = first byte of frame k, [n_frames] = total
+ *   status        DEVICE  uint32_t[TRPX_STATUS_WORDS] (see above); word 1 = prolix_bits
+ *   workspace     DEVICE  >= trpx_encode_workspace_bytes(...), 16-byte aligned
+ *
+ * If the stack does not fit out_capacity nothing is written to `out`, frame_offsets is still
+ * valid and status[0] = TRPX_ERR_CAPACITY (sizes-only query: pass out_capacity = 0).
+ */
+int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block,
+                uint8_t* out, size_t out_capacity, uint64_t* frame_offsets, uint32_t* status,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Decode n_frames frames.  Replaces jpa::Terse::prolix(Iterator, frame) (Terse.hpp:352-389),
+ * f_find_terse_frame (Terse.hpp:562-585, intended semantics: offset_k = sum of S_j, j < k) and
+ * Bit_range::get_range / operator T() (Bit_pointer.hpp:742-792, :597-617).
+ *
+ *   stream_signed  the header's `signed` attribute; must equal trpx_dtype_is_signed(out_dtype)
+ *                  (same-type decode is the reference's contract)
+ *   terse          DEVICE const uint8_t[terse_bytes], 4-byte aligned
+ *   frame_offsets  DEVICE const uint64_t[n_frames + 1], or NULL: the frames are then located by
+ *                  a serial header walk on the device (the .trpx format stores no index)
+ *   pixels_out     DEVICE T[n_frames * n_values], 16-byte aligned
+ *   status         DEVICE uint32_t[TRPX_STATUS_WORDS]; word 0 = TRPX_ERR_CORRUPT if a frame's
+ *                  bits run past its end (the reference does not check; we do)
+ */
+int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block,
+                void* pixels_out, uint32_t* status, void* workspace, size_t workspace_bytes,
+                void* stream);
+
+/*
+ * Host-pointer convenience wrappers (what the C++ trpx::Terse class calls): allocate device
+ * staging, copy in, run the device entry point, copy out, synchronise.  `out` must hold
+ * n_frames * trpx_worst_case_bytes(); *total_bytes receives sum(S_f); frame_offsets (host,
+ * n_frames + 1) and prolix_bits may be NULL.  device < 0 keeps the current HIP device.
+ */
+int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_frames,
+                     unsigned block, uint8_t* out, size_t out_capacity, size_t* total_bytes,
+                     uint64_t* frame_offsets, uint32_t* prolix_bits, int device);
+int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                     const uint64_t* frame_offsets, size_t n_values, size_t n_frames,
+                     unsigned block, void* pixels_out, int device);
+
+/*
+ * Locate the frames of a stack that comes without an index (a .trpx file): serial header walk on
+ * the device, the intended semantics of jpa::Terse::f_find_terse_frame (Terse.hpp:562-585).
+ * frame_offsets: HOST uint64_t[n_frames + 1].  max_bits = widest legal block (8, 16 or 32).
+ */
+int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_values, size_t n_frames,
+                            unsigned block, unsigned max_bits, uint64_t* frame_offsets, int device);
+
+/*
+ * synth-v1 frame generator (SURVEY.md section 8 row d) -- bench/test utility so that the GPU
+ * box regenerates exactly the pixels the oracle anchors were computed on.  dtype U16 or I32.
+ */
+int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
+                    void* pixels_dev, void* stream);
+
+/*
+ * Per-kernel timing for bench.py's roofline leg.  While enabled (per calling thread), trpx_encode /
+ * trpx_decode record a hipEvent on `stream` before their first and after each of their kernels;
+ * trpx_profile_read waits for the last launch and returns the elapsed ms of each stage
+ * (encode: tile_bits, frame_scan, stack_scan, zero_edges, pack; decode: walk, unpack).
+ * Returns the number of stages written.  Not graph-capturable while enabled.
+ */
+int trpx_profile_enable(int on);
+int trpx_profile_read(float* stage_ms, int capacity);
+
+/* ---- stream-serialise surface: the ASCII header of Terse::write (Terse.hpp:454-474) and its
+ * reader (Terse.hpp:485-498 over XML_element.hpp:216-224, :296-307).  Host only. ------------ */
+typedef struct trpx_header {
+    unsigned prolix_bits;
+    int      is_signed;
+    unsigned block;
+    uint64_t memory_size;       /* payload bytes following the header            */
+    uint64_t number_of_values;  /* per frame                                     */
+    uint64_t number_of_frames;
+    unsigned n_dims;            /* 0 = no `dimensions` attribute                 */
+    uint64_t dims[8];
+} trpx_header;
+
+/* Writes the exact header text of Terse::write into buf (NUL-terminated); returns its length
+ * (excluding the NUL) or 0 if buf_cap is too small. */
+size_t trpx_header_format(const trpx_header* h, char* buf, size_t buf_cap);
+/* Finds "<Terse" in data[0..len), parses the attributes (unknown ones are ignored, as the
+ * reference does) and sets *payload_offset to the byte after "/>".  number_of_frames is
+ * mandatory. */
+int trpx_header_parse(const char* data, size_t len, trpx_header* h, size_t* payload_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRPX_HIP_H */

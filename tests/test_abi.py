@@ -1,0 +1,109 @@
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/trpx_hip.h
+declares, its pure-arithmetic / text entry points work, and compute entry points FAIL LOUDLY
+without a device (no CPU fallback exists in the product)."""
+import ctypes as C
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "trpx_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trpx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from trpx_amd import _lib
+    L = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"libtrpx_hip.so does not export {n}"
+    assert set(names) == set(_lib.SYMBOLS), "python binding table out of sync with the header"
+    assert L.trpx_abi_version() == 1
+
+
+def test_pure_arithmetic_entry_points(oracle):
+    from trpx_amd import _lib
+    L = _lib.lib()
+    assert [L.trpx_dtype_size(d) for d in range(6)] == [1, 1, 2, 2, 4, 4]
+    assert L.trpx_dtype_size(17) == 0
+    assert [L.trpx_dtype_is_signed(d) for d in range(6)] == [0, 1, 0, 1, 0, 1]
+    for dt, code in ((np.uint8, 0), (np.uint16, 2), (np.int32, 5)):
+        for n in (1, 12, 13, 262144, 4096 * 4096):
+            assert L.trpx_worst_case_bytes(code, n, 12) == oracle.worst_case_bytes(dt, n)
+    assert L.trpx_worst_case_bytes(2, 262144, 12) == 524288 + (12 * 21846 + 7) // 8 + 1
+    assert L.trpx_encode_workspace_bytes(2, 262144, 2000, 12) > 0
+    assert L.trpx_decode_workspace_bytes(2, 262144, 2000, 12) > 2000 * 21846
+    assert L.trpx_encode_workspace_bytes(2, 262144, 2000, 7) == 0      # block != 12: unsupported on the GPU path
+
+
+def test_header_text_matches_reference_goldens(golden):
+    from trpx_amd import _lib
+    L = _lib.lib()
+    for c in golden["cases"] + [golden["stack"]]:
+        m = dict(re.findall(r'(\w+)="([^"]*)"', c["header"]))
+        h = _lib.trpx_header()
+        h.prolix_bits, h.is_signed, h.block = int(m["prolix_bits"]), int(m["signed"]), int(m["block"])
+        h.memory_size, h.number_of_values = int(m["memory_size"]), int(m["number_of_values"])
+        h.number_of_frames = int(m["number_of_frames"])
+        dims = [int(x) for x in m.get("dimensions", "").split()]
+        h.n_dims = len(dims)
+        for i, d in enumerate(dims):
+            h.dims[i] = d
+        buf = C.create_string_buffer(512)
+        n = L.trpx_header_format(C.byref(h), buf, 512)
+        assert buf.raw[:n].decode() == c["header"], c["name"]
+        # and back, with junk in front and a payload behind (XML_element.hpp:442-452)
+        blob = b"junk <Ters <!-- x -->" + c["header"].encode() + b"\x00\x01payload"
+        h2, off = _lib.trpx_header(), C.c_size_t(0)
+        assert L.trpx_header_parse(blob, len(blob), C.byref(h2), C.byref(off)) == 0
+        assert blob[off.value:] == b"\x00\x01payload"
+        for f in ("prolix_bits", "is_signed", "block", "memory_size", "number_of_values", "number_of_frames", "n_dims"):
+            assert getattr(h2, f) == getattr(h, f), (c["name"], f)
+        assert list(h2.dims)[:h2.n_dims] == dims
+
+
+def test_header_parse_tolerates_unknown_attributes_and_order():
+    from trpx_amd import _lib
+    L = _lib.lib()
+    blob = (b"<Terse frame_sizes='5 6' number_of_frames=\"2\" number_of_values=\"7\" memory_size=\"11\" "
+            b"block=\"12\" signed='0' prolix_bits=\"3\"/>XYZ")
+    h, off = _lib.trpx_header(), C.c_size_t(0)
+    assert L.trpx_header_parse(blob, len(blob), C.byref(h), C.byref(off)) == 0
+    assert (h.number_of_frames, h.number_of_values, h.memory_size, h.block, h.is_signed, h.prolix_bits) == (2, 7, 11, 12, 0, 3)
+    assert blob[off.value:] == b"XYZ"
+    # missing number_of_frames: the reference's stoull("") throws -> error here
+    bad = b'<Terse prolix_bits="3" signed="0" block="12" memory_size="11" number_of_values="7"/>'
+    assert L.trpx_header_parse(bad, len(bad), C.byref(h), C.byref(off)) != 0
+    assert L.trpx_header_parse(b"no header here", 14, C.byref(h), C.byref(off)) != 0
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from trpx_amd import Terse, TrpxError, _lib
+    with pytest.raises(TrpxError) as e:
+        Terse(np.arange(100, dtype=np.uint16))
+    assert e.value.code in (_lib.ERR_NO_DEVICE, _lib.ERR_HIP)
+
+
+def test_argument_validation_without_gpu():
+    from trpx_amd import _lib
+    L = _lib.lib()
+    # block != 12 is rejected before anything touches a device
+    rc = L.trpx_encode(2, 16, 100, 1, 7, 16, 0, 16, 16, 16, 1 << 20, None)
+    assert rc == _lib.ERR_UNSUPPORTED and b"block" in L.trpx_last_error_string()
+    rc = L.trpx_encode(9, 16, 100, 1, 12, 16, 0, 16, 16, 16, 1 << 20, None)
+    assert rc == _lib.ERR_INVALID_ARG
+    rc = L.trpx_decode(1, 2, 16, 10, None, 100, 1, 12, 16, 16, 16, 1 << 20, None)   # signed stream -> u16
+    assert rc == _lib.ERR_UNSUPPORTED
+    rc = L.trpx_encode(2, 16, 100, 1, 12, 16, 0, 16, 16, 16, 8, None)                # workspace too small
+    assert rc == _lib.ERR_CAPACITY

@@ -1,0 +1,279 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: bit-exact streams, frame sizes and prolix_bits on encode; pixel-exact on decode.
+Small cases: golden fixtures made by the real reference + seeded differential runs against the
+oracle.  Full BASELINE sizes: synth-v1 anchors (FNV hashes / byte totals computed with the real
+reference) and size-independent properties (encode -> decode round trip, stack == concatenation
+of single-frame encodes, sizes == prefix differences)."""
+import ctypes as C
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL_DTYPES = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32]
+
+
+def _host_encode(px2d):
+    """[frames, n] numpy -> (stream bytes, offsets, prolix_bits) through trpx_encode_host."""
+    from trpx_amd import _lib
+    from trpx_amd.terse import _code
+    L = _lib.lib()
+    px2d = np.ascontiguousarray(px2d)
+    f, n = px2d.shape
+    cap = f * L.trpx_worst_case_bytes(_code(px2d.dtype), n, 12)
+    out = np.full(cap, 0xAA, np.uint8)     # poisoned: every output byte must be written
+    total, pb = C.c_size_t(0), C.c_uint(0)
+    offs = np.zeros(f + 1, np.uint64)
+    _lib.check(L.trpx_encode_host(_code(px2d.dtype), px2d.ctypes.data, n, f, 12, out.ctypes.data, cap,
+                                  C.byref(total), offs.ctypes.data, C.byref(pb), -1))
+    return out[: total.value].copy(), offs, int(pb.value)
+
+
+def _host_decode(stream, offs, n, frames, dtype):
+    from trpx_amd import _lib
+    from trpx_amd.terse import _code
+    L = _lib.lib()
+    out = np.full((frames, n), 0x55, np.dtype(dtype))
+    stream = np.ascontiguousarray(stream)
+    _lib.check(L.trpx_decode_host(int(np.dtype(dtype).kind == "i"), _code(dtype), stream.ctypes.data, stream.size,
+                                  offs.ctypes.data if offs is not None else None, n, frames, 12,
+                                  out.ctypes.data, -1))
+    return out
+
+
+def test_golden_fixtures_through_c_abi(gpu, golden):
+    n_checked = 0
+    for c in golden["cases"]:
+        if c["block"] != 12:
+            continue
+        px = np.array(c["pixels"], np.dtype(c["dtype"]))
+        s, offs, pb = _host_encode(px.reshape(1, -1))
+        assert s.tobytes().hex() == c["stream"], c["name"]
+        assert pb == c["prolix_bits"], c["name"]
+        assert int(offs[1]) == len(c["stream"]) // 2
+        want = np.frombuffer(bytes.fromhex(c["stream"]), np.uint8)
+        assert (_host_decode(want, None, px.size, 1, px.dtype)[0] == px).all(), c["name"]
+        n_checked += 1
+    assert n_checked >= 30
+
+
+def test_golden_stack_layout(gpu, golden):
+    st = golden["stack"]
+    px = np.array(st["pixels"], np.uint16)
+    s, offs, pb = _host_encode(px)
+    assert s.tobytes().hex() == st["stream"]
+    assert [int(x) for x in np.diff(offs)] == st["frame_sizes"]
+    # decode with the offsets, and without (serial walk, the .trpx file case)
+    assert (_host_decode(s, offs, px.shape[1], 3, np.uint16) == px).all()
+    assert (_host_decode(s, None, px.shape[1], 3, np.uint16) == px).all()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_differential_vs_oracle_all_dtypes(gpu, oracle, dtype):
+    rng = np.random.RandomState(11)
+    dt = np.dtype(dtype)
+    bits = dt.itemsize * 8
+    top = bits - 1 if dt.kind == "i" else bits            # full width incl. cases outside the reference's D3 domain
+    for n in (1, 5, 12, 13, 255 * 12, 256 * 12, 256 * 12 + 1, 3073, 7000, 12289):
+        for frames in (1, 3):
+            for hi in (0, 2, 7, min(top, 10), top):
+                mag = rng.randint(0, 1 << hi, size=(frames, n), dtype=np.int64) if hi else np.zeros((frames, n), np.int64)
+                if dt.kind == "i":
+                    mag = mag * rng.choice([-1, 1], size=(frames, n))
+                px = mag.astype(dt)
+                if hi and rng.rand() < 0.5:                # blocks of zeros / runs of equal widths
+                    px[:, : n // 2] = 0
+                want, sizes, pb = oracle.encode_stack(px)
+                got, offs, gpb = _host_encode(px)
+                assert got.size == want.size and (np.diff(offs).astype(np.uint64) == sizes).all(), (dtype, n, frames, hi)
+                assert (got == want).all(), (dtype, n, frames, hi)
+                assert gpb == pb
+                assert (_host_decode(want, offs, n, frames, dt) == px).all(), (dtype, n, frames, hi)
+
+
+def test_type_extremes_round_trip(gpu, oracle):
+    # outside the reference's validity domain (D3): oracle == GPU == mathematically consistent extension
+    for dt in (np.int16, np.int32, np.int8):
+        info = np.iinfo(dt)
+        px = np.array([info.min, info.max, -1, 0, 1, info.min + 1] * 7, dt).reshape(1, -1)
+        want, sizes, pb = oracle.encode_stack(px)
+        got, offs, gpb = _host_encode(px)
+        assert (got == want).all() and gpb == pb == info.bits
+        assert (_host_decode(got, offs, px.shape[1], 1, dt) == px).all()
+    px = np.array([0xFFFFFFFF, 0x80000000, 1, 0] * 5, np.uint32).reshape(1, -1)
+    got, offs, gpb = _host_encode(px)
+    assert gpb == 32 and (got == oracle.encode_stack(px)[0]).all()
+    assert (_host_decode(got, offs, px.shape[1], 1, np.uint32) == px).all()
+
+
+def test_unaligned_frame_sizes_take_the_scalar_path(gpu, oracle):
+    # n % 4 != 0 -> frames are not vector aligned
+    rng = np.random.RandomState(3)
+    for n in (13, 4097, 10001):
+        px = rng.poisson(5, size=(4, n)).astype(np.uint16)
+        want, sizes, pb = oracle.encode_stack(px)
+        got, offs, _ = _host_encode(px)
+        assert (got == want).all()
+        assert (_host_decode(got, offs, n, 4, np.uint16) == px).all()
+        assert (_host_decode(got, None, n, 4, np.uint16) == px).all()
+
+
+def test_synth_generator_matches_oracle(gpu, oracle):
+    from trpx_amd import codec
+    for dt, n in ((np.uint16, 512 * 512), (np.int32, 300 * 300)):
+        dev = codec.synth(dt, 5, 3, n, device=gpu).cpu().numpy()
+        assert (dev == oracle.synth(dt, 5, 3, n)).all()
+
+
+def test_synth_anchors_u16_512(gpu, golden):
+    """configs[1]/[2] data: GPU stream of frames 0..2 hashes to what the REAL reference produced."""
+    import torch
+    from trpx_amd import codec
+    from oracle import oracle as O
+    n = 512 * 512
+    px = codec.synth(np.uint16, 0, 16, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    offs = enc.frame_offsets.cpu().numpy()
+    data = enc.stack().cpu().numpy()
+    assert int(offs[-1]) == golden["synth_u16_first16_total_bytes"]
+    assert enc.prolix_bits() == 12
+    for a in golden["anchors"]:
+        if a["dtype"] != "uint16":
+            continue
+        f = a["frame"]
+        s = data[offs[f]:offs[f + 1]]
+        assert s.size == a["size"]
+        assert f"{O.fnv1a64(s):016x}" == a["stream_fnv"]
+        assert s[:16].tobytes().hex() == a["first16"]
+    back, status = codec.decode(enc.stack(), enc.frame_offsets, n, 16, np.uint16)
+    torch.cuda.synchronize()
+    assert int(status[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
+
+
+def test_synth_anchor_i32_4096(gpu, golden):
+    """configs[3]: 4096x4096 int32 with sparse peaks (wide bit-width / 12-bit header path)."""
+    import torch
+    from trpx_amd import codec
+    from oracle import oracle as O
+    a = [x for x in golden["anchors"] if x["dtype"] == "int32"][0]
+    n = a["n"]
+    px = codec.synth(np.int32, 0, 2, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    offs = enc.frame_offsets.cpu().numpy()
+    s = enc.data[: offs[1]].cpu().numpy()
+    assert s.size == a["size"] and enc.prolix_bits() == a["prolix_bits"]
+    assert f"{O.fnv1a64(s):016x}" == a["stream_fnv"]
+    back, status = codec.decode(enc.stack(), enc.frame_offsets, n, 2, np.int32)
+    torch.cuda.synchronize()
+    assert int(status[0].item()) == 0 and torch.equal(back, px)
+
+
+def test_full_stack_2000_frames_properties(gpu):
+    """configs[1]+[2] at full size: total bytes == the reference's 203 596 114, round trip exact,
+    every frame of the stack == its own single-frame encode (checked on a sample)."""
+    import torch
+    from trpx_amd import codec
+    n, frames = 512 * 512, 2000
+    px = codec.synth(np.uint16, 0, frames, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    assert enc.total_bytes() == 203596114          # SURVEY.md section 8 row d, computed with the real reference
+    assert enc.prolix_bits() == 12
+    offs = enc.frame_offsets
+    assert int(offs[0].item()) == 0 and bool((offs[1:] > offs[:-1]).all())
+    back, status = codec.decode(enc.stack(), offs, n, frames, np.uint16)
+    torch.cuda.synchronize()
+    assert int(status[0].item()) == 0
+    assert torch.equal(back.view(torch.int16), px.view(torch.int16))
+    for f in (0, 1, 999, 1999):
+        single = codec.encode(px[f:f + 1])
+        torch.cuda.synchronize()
+        a, b = int(offs[f].item()), int(offs[f + 1].item())
+        assert single.total_bytes() == b - a
+        assert torch.equal(single.stack(), enc.data[a:b])
+
+
+def test_capacity_error_and_sizes_only_query(gpu):
+    import torch
+    from trpx_amd import codec, _lib
+    px = codec.synth(np.uint16, 0, 4, 512 * 512, device=gpu)
+    small = torch.full((1024,), 7, dtype=torch.uint8, device=gpu)
+    enc = codec.encode(px, out=small)
+    torch.cuda.synchronize()
+    assert int(enc.status[0].item()) == _lib.ERR_CAPACITY
+    assert bool((small == 7).all()), "nothing may be written when the stack does not fit"
+    full = codec.encode(px)
+    torch.cuda.synchronize()
+    assert torch.equal(full.frame_offsets, enc.frame_offsets), "sizes must still be reported"
+
+
+def test_corrupt_and_truncated_streams_are_detected(gpu, oracle):
+    from trpx_amd import _lib, TrpxError
+    rng = np.random.RandomState(5)
+    px = rng.poisson(4, size=(2, 5000)).astype(np.uint16)
+    s, offs, _ = _host_encode(px)
+    with pytest.raises(TrpxError) as e:                    # truncated
+        _host_decode(s[: s.size - 40], None, 5000, 2, np.uint16)
+    assert e.value.code == _lib.ERR_CORRUPT
+    bad_offs = offs.copy()
+    bad_offs[1] -= 3                                       # frame boundary in the wrong place
+    with pytest.raises(TrpxError):
+        _host_decode(s, bad_offs, 5000, 2, np.uint16)
+
+
+def test_terse_class_mirrors_reference_surface(gpu, oracle, golden, tmp_path):
+    from trpx_amd import Terse
+    # README example (Terse.hpp:127-154)
+    numbers = np.arange(-500, 500, dtype=np.int32)
+    t = Terse(numbers)
+    assert (t.terse_size(), t.bits_per_val(), t.is_signed(), t.size(), t.number_of_frames()) == (1152, 10, True, 1000, 1)
+    buf = io.BytesIO()
+    t.write(buf)
+    want_hdr = ('<Terse prolix_bits="10" signed="1" block="12" memory_size="1152" number_of_values="1000" '
+                'number_of_frames="1"/>')
+    assert buf.getvalue().startswith(want_hdr.encode())
+    buf.seek(0)
+    r = Terse.read(buf)
+    assert (r.prolix(np.empty(1000, np.int32)) == numbers).all()
+    assert buf.read() == b""                               # stream left right after the payload
+    # multi-frame with dims == the reference's own push_back stack file, byte for byte
+    st = golden["stack"]
+    px = np.array(st["pixels"], np.uint16).reshape(3, *st["dims"])
+    t = Terse()
+    for f in range(3):
+        t.push_back(px[f])
+    assert t.dim() == st["dims"]
+    out = io.BytesIO()
+    t.write(out)
+    assert out.getvalue() == st["header"].encode() + bytes.fromhex(st["stream"])
+    out.seek(0)
+    r = Terse.read(out)
+    assert r.frame_sizes() == st["frame_sizes"] and r.dim() == st["dims"]
+    for f in (2, 0, 1):                                    # out-of-order access works (reference defect D1)
+        assert (r.prolix(np.empty(700, np.uint16), f) == px[f].reshape(-1)).all()
+    assert (r.prolix_stack(np.uint16) == px.reshape(3, -1)).all()
+    # error conventions
+    with pytest.raises(ValueError):
+        t.push_back(np.zeros(10, np.uint16))
+    with pytest.raises(ValueError):
+        t.prolix(np.empty(700, np.uint16), 3)
+    with pytest.raises(ValueError):
+        Terse(np.arange(-5, 5, dtype=np.int16)).prolix(np.empty(10, np.uint16))
+
+
+def test_cpp_drop_in_example(gpu, tmp_path):
+    exe = os.path.join(ROOT, "tests", "cpp", "terse_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    r = subprocess.run([exe, str(tmp_path / "junk.terse")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

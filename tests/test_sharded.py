@@ -1,0 +1,70 @@
+"""CPU test of the N>1 path: world_size-2 gloo processes run the size gather / global offset
+logic of trpx_amd.sharded on (oracle-encoded) shards and the result equals the single-process stack."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_frames, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from trpx_amd import sharded
+    n = 3000
+    lo, hi = sharded.frame_range(total_frames, rank, world)
+    px = O.synth(np.uint16, lo, hi - lo, n)
+    data, sizes, pb = O.encode_stack(px)                    # stands in for the GPU encode of this shard
+    local_offsets = torch.zeros(hi - lo + 1, dtype=torch.int64)
+    local_offsets[1:] = torch.cumsum(torch.from_numpy(sizes.astype(np.int64)), 0)
+    goffs, base, gpb = sharded.gather_global_offsets(local_offsets, torch.tensor([pb]))
+    q.put((rank, goffs.numpy().copy(), int(base), int(gpb), data.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_size_gather_matches_single_process_stack():
+    from oracle import oracle as O
+    world, total_frames, n = 2, 7, 3000                     # ragged: 3 + 4 frames
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want, sizes, pb = O.encode_stack(O.synth(np.uint16, 0, total_frames, n))
+    want_offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    assembled = bytearray(want.size)
+    for rank, goffs, base, gpb, data in res:
+        assert (goffs == want_offs).all()
+        assert gpb == pb
+        assembled[base:base + len(data)] = data             # each rank writes its shard at its global offset
+    assert bytes(assembled) == want.tobytes()
+
+
+def test_frame_range_partitions_exactly():
+    from trpx_amd import sharded
+    for total in (1, 7, 2000, 16000):
+        for world in (1, 2, 4, 8):
+            r = [sharded.frame_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+    assert sharded.frame_range(16000, 3, 8) == (6000, 8000)

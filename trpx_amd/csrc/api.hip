@@ -1,0 +1,317 @@
+// C ABI of libtrpx_hip.so (declared in include/trpx_hip.h).  Thin: argument checks, workspace
+// carving, kernel launches on the caller's stream.  No CPU codec lives here: without a gfx950
+// device every compute entry point fails with TRPX_ERR_NO_DEVICE / TRPX_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/trpx_hip.h"
+#include "encode_kernels.hpp"
+#include "profile.hpp"
+
+namespace trpx {
+Profiler& profiler() {
+    static thread_local Profiler p;
+    return p;
+}
+}  // namespace trpx
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(TRPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+bool geom_of(size_t n_values, unsigned block, trpx::FrameGeom* g) {
+    if (n_values == 0 || block != (unsigned)trpx::kBlock) return false;
+    const uint64_t nb = (n_values + trpx::kBlock - 1) / trpx::kBlock;
+    if (nb > 0xFFFFFFFFull) return false;
+    g->n_values = n_values;
+    g->n_blocks = (uint32_t)nb;
+    g->n_tiles = (uint32_t)((nb + trpx::kTileBlocks - 1) / trpx::kTileBlocks);
+    return true;
+}
+
+// workspace layouts ------------------------------------------------------------------------
+struct EncWs { size_t frame_size, tile_off, tile_bits, total; };
+EncWs enc_ws(const trpx::FrameGeom& g, size_t n_frames) {
+    EncWs w;
+    const size_t tiles = n_frames * (size_t)g.n_tiles;
+    w.frame_size = 0;
+    w.tile_off = trpx::align_up(w.frame_size + 8 * n_frames, 16);
+    w.tile_bits = trpx::align_up(w.tile_off + 8 * tiles, 16);
+    w.total = trpx::align_up(w.tile_bits + 4 * tiles, 256);
+    return w;
+}
+struct DecWs { size_t walk_offsets, tile_off, widths, total; };
+DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
+    DecWs w;
+    const size_t tiles = n_frames * (size_t)g.n_tiles;
+    w.walk_offsets = 0;
+    w.tile_off = trpx::align_up(w.walk_offsets + 8 * (n_frames + 1), 16);
+    w.widths = trpx::align_up(w.tile_off + 8 * tiles, 16);
+    w.total = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trpx_abi_version(void) { return TRPX_ABI_VERSION; }
+const char* trpx_last_error_string(void) { return g_err; }
+
+size_t trpx_dtype_size(int dtype) {
+    switch (dtype) {
+    case TRPX_U8: case TRPX_I8: return 1;
+    case TRPX_U16: case TRPX_I16: return 2;
+    case TRPX_U32: case TRPX_I32: return 4;
+    }
+    return 0;
+}
+int trpx_dtype_is_signed(int dtype) { return dtype >= 0 && dtype <= TRPX_I32 ? (dtype & 1) : 0; }
+
+int trpx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t trpx_worst_case_bytes(int dtype, size_t n_values, unsigned block) {
+    const size_t es = trpx_dtype_size(dtype);
+    if (!es || !block) return 0;
+    const size_t nblocks = (n_values + block - 1) / block;
+    return n_values * es + (12 * nblocks + 7) / 8 + 1;
+}
+
+size_t trpx_encode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g)) return 0;
+    return enc_ws(g, n_frames).total;
+}
+size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g)) return 0;
+    return dec_ws(g, n_frames).total;
+}
+
+int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
+                size_t out_capacity, uint64_t* frame_offsets, uint32_t* status, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: unknown dtype %d", dtype);
+    if (block != (unsigned)trpx::kBlock)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode: block=%u (the GPU path implements the format's default block=12, Terse.hpp:264)", block);
+    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
+    if (!pixels || !frame_offsets || !status || !workspace || (!out && out_capacity))
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: null pointer");
+    if (((uintptr_t)out | (uintptr_t)workspace | (uintptr_t)frame_offsets) % 8 || (uintptr_t)out % 16 ||
+        (uintptr_t)status % 4 || (uintptr_t)pixels % trpx_dtype_size(dtype))
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: misaligned pointer (out needs 16 B, workspace/offsets 8 B)");
+    const EncWs w = enc_ws(g, n_frames);
+    if (workspace_bytes < w.total)
+        return fail(TRPX_ERR_CAPACITY, "trpx_encode: workspace %zu < %zu", workspace_bytes, w.total);
+
+    trpx::EncodeArgs a;
+    a.pixels = pixels;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.out = out;
+    a.out_capacity = out_capacity;
+    a.frame_offsets = frame_offsets;
+    a.status = status;
+    char* ws = static_cast<char*>(workspace);
+    a.frame_size = reinterpret_cast<uint64_t*>(ws + w.frame_size);
+    a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
+    a.tile_bits = reinterpret_cast<uint32_t*>(ws + w.tile_bits);
+    HIP_TRY(trpx::launch_encode(dtype, a, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
+                uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(out_dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: unknown dtype %d", out_dtype);
+    if (block != (unsigned)trpx::kBlock)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: block=%u (GPU path implements block=12)", block);
+    if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: stream signed=%d into dtype %d: only same-signedness decode "
+                    "is defined by the reference (Terse.hpp:356-357)", stream_signed, out_dtype);
+    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: bad sizes");
+    if (!terse || !pixels_out || !status || !workspace) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: null pointer");
+    if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 ||
+        (uintptr_t)pixels_out % trpx_dtype_size(out_dtype))
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: misaligned pointer (terse needs 4 B, workspace 8 B)");
+    const DecWs w = dec_ws(g, n_frames);
+    if (workspace_bytes < w.total)
+        return fail(TRPX_ERR_CAPACITY, "trpx_decode: workspace %zu < %zu", workspace_bytes, w.total);
+
+    trpx::DecodeArgs a;
+    a.terse = terse;
+    a.terse_bytes = terse_bytes;
+    a.frame_offsets = frame_offsets;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.pixels_out = pixels_out;
+    a.status = status;
+    char* ws = static_cast<char*>(workspace);
+    a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
+    a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
+    a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
+    HIP_TRY(trpx::launch_decode(out_dtype, a, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+int trpx_profile_enable(int on) {
+    trpx::profiler().enabled = on != 0;
+    return TRPX_OK;
+}
+int trpx_profile_read(float* stage_ms, int capacity) {
+    if (!stage_ms || capacity <= 0) return 0;
+    return trpx::profiler().read(stage_ms, capacity);
+}
+
+int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values, void* pixels_dev,
+                    void* stream) {
+    if (dtype != TRPX_U16 && dtype != TRPX_I32)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_synth_fill: synth-v1 is defined for U16 and I32");
+    if (!pixels_dev) return fail(TRPX_ERR_INVALID_ARG, "trpx_synth_fill: null pointer");
+    HIP_TRY(trpx::launch_synth(dtype, seed, frame0, n_frames, n_values, pixels_dev, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+// ---- host-pointer convenience wrappers ---------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+}  // namespace
+
+int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
+                     size_t out_capacity, size_t* total_bytes, uint64_t* frame_offsets, uint32_t* prolix_bits,
+                     int device) {
+    if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_encode_host: no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    const size_t es = trpx_dtype_size(dtype);
+    if (!es || !pixels || !out || !total_bytes) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode_host: bad argument");
+    const size_t in_bytes = n_values * n_frames * es;
+    const size_t cap = trpx::align_up(n_frames * trpx_worst_case_bytes(dtype, n_values, block), 16);
+    const size_t ws_bytes = trpx_encode_workspace_bytes(dtype, n_values, n_frames, block);
+    if (!ws_bytes) return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
+                               "trpx_encode_host: unsupported sizes/block (block=%u)", block);
+    DevBuf d_px, d_out, d_off, d_st, d_ws;
+    HIP_TRY(d_px.alloc(in_bytes));
+    HIP_TRY(d_out.alloc(cap));
+    HIP_TRY(d_off.alloc(8 * (n_frames + 1)));
+    HIP_TRY(d_st.alloc(4 * TRPX_STATUS_WORDS));
+    HIP_TRY(d_ws.alloc(ws_bytes));
+    HIP_TRY(hipMemcpy(d_px.p, pixels, in_bytes, hipMemcpyHostToDevice));
+    int rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
+                         static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t st[TRPX_STATUS_WORDS];
+    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0]) return fail((int)st[0], "trpx_encode_host: device status %u", st[0]);
+    std::vector<uint64_t> offs(n_frames + 1);
+    HIP_TRY(hipMemcpy(offs.data(), d_off.p, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
+    const size_t total = (size_t)offs[n_frames];
+    if (total > out_capacity) return fail(TRPX_ERR_CAPACITY, "trpx_encode_host: need %zu bytes, have %zu", total, out_capacity);
+    HIP_TRY(hipMemcpy(out, d_out.p, total, hipMemcpyDeviceToHost));
+    *total_bytes = total;
+    if (frame_offsets) memcpy(frame_offsets, offs.data(), 8 * (n_frames + 1));
+    if (prolix_bits) *prolix_bits = st[1];
+    return TRPX_OK;
+}
+
+int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                     const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block,
+                     void* pixels_out, int device) {
+    if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_decode_host: no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    const size_t es = trpx_dtype_size(out_dtype);
+    if (!es || !terse || !pixels_out || !terse_bytes) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_host: bad argument");
+    const size_t out_bytes = n_values * n_frames * es;
+    const size_t ws_bytes = trpx_decode_workspace_bytes(out_dtype, n_values, n_frames, block);
+    if (!ws_bytes) return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
+                               "trpx_decode_host: unsupported sizes/block (block=%u)", block);
+    DevBuf d_in, d_out, d_off, d_st, d_ws;
+    HIP_TRY(d_in.alloc(trpx::align_up(terse_bytes, 4) + 8));
+    HIP_TRY(d_out.alloc(out_bytes));
+    HIP_TRY(d_st.alloc(4 * TRPX_STATUS_WORDS));
+    HIP_TRY(d_ws.alloc(ws_bytes));
+    HIP_TRY(hipMemset(d_in.p, 0, trpx::align_up(terse_bytes, 4) + 8));
+    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    if (frame_offsets) {
+        HIP_TRY(d_off.alloc(8 * (n_frames + 1)));
+        HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
+    }
+    int rc = trpx_decode(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes,
+                         frame_offsets ? static_cast<const uint64_t*>(d_off.p) : nullptr, n_values, n_frames, block,
+                         d_out.p, static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t st[TRPX_STATUS_WORDS];
+    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0]) return fail((int)st[0], "trpx_decode_host: corrupt or truncated stream (device status %u)", st[0]);
+    HIP_TRY(hipMemcpy(pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    return TRPX_OK;
+}
+
+int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_values, size_t n_frames,
+                            unsigned block, unsigned max_bits, uint64_t* frame_offsets, int device) {
+    if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_frame_offsets_host: no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    trpx::FrameGeom g;
+    if (!terse || !terse_bytes || !frame_offsets || !n_frames || max_bits == 0 || max_bits > 32)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_frame_offsets_host: bad argument");
+    if (!geom_of(n_values, block, &g))
+        return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
+                    "trpx_frame_offsets_host: unsupported sizes/block (block=%u)", block);
+    const DecWs w = dec_ws(g, n_frames);
+    DevBuf d_in, d_st, d_ws;
+    HIP_TRY(d_in.alloc(trpx::align_up(terse_bytes, 4) + 8));
+    HIP_TRY(d_st.alloc(4 * TRPX_STATUS_WORDS));
+    HIP_TRY(d_ws.alloc(w.total));
+    HIP_TRY(hipMemset(d_in.p, 0, trpx::align_up(terse_bytes, 4) + 8));
+    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    trpx::DecodeArgs a;
+    a.terse = static_cast<const uint8_t*>(d_in.p);
+    a.terse_bytes = terse_bytes;
+    a.frame_offsets = nullptr;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.pixels_out = nullptr;
+    a.status = static_cast<uint32_t*>(d_st.p);
+    char* ws = static_cast<char*>(d_ws.p);
+    a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
+    a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
+    a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
+    HIP_TRY(trpx::launch_walk_serial(a, max_bits, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t st[TRPX_STATUS_WORDS];
+    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0]) return fail((int)st[0], "trpx_frame_offsets_host: corrupt or truncated stack");
+    HIP_TRY(hipMemcpy(frame_offsets, a.walk_offsets, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
+    return TRPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Shared device-side definitions of the TERSE/PROLIX kernels (gfx950 / CDNA4 only).
+//
+// Geometry: the codec block is 12 values (Terse.hpp:264,:478).  One lane owns one block, one
+// 64-lane wavefront owns 64 consecutive blocks, one 256-thread workgroup owns a TILE of 256
+// consecutive blocks (3072 values) of ONE frame.  Frames never share a tile: the header state
+// resets per frame (Terse.hpp:505,:359) and frames start byte aligned (Terse.hpp:502-504).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trpx {
+
+constexpr int kBlock = 12;          // values per codec block on the tuned path
+constexpr int kWave = 64;
+constexpr int kThreads = 256;       // threads per workgroup = blocks per tile
+constexpr int kTileBlocks = kThreads;
+constexpr int kTileValues = kTileBlocks * kBlock;
+
+struct FrameGeom {
+    uint64_t n_values;   // per frame
+    uint32_t n_blocks;   // ceil(n_values / 12)
+    uint32_t n_tiles;    // ceil(n_blocks / 256)
+};
+
+template <typename T> struct PixelTraits;
+template <> struct PixelTraits<uint8_t>  { using U = uint8_t;  static constexpr int bits = 8;  static constexpr bool is_signed = false; };
+template <> struct PixelTraits<int8_t>   { using U = uint8_t;  static constexpr int bits = 8;  static constexpr bool is_signed = true;  };
+template <> struct PixelTraits<uint16_t> { using U = uint16_t; static constexpr int bits = 16; static constexpr bool is_signed = false; };
+template <> struct PixelTraits<int16_t>  { using U = uint16_t; static constexpr int bits = 16; static constexpr bool is_signed = true;  };
+template <> struct PixelTraits<uint32_t> { using U = uint32_t; static constexpr int bits = 32; static constexpr bool is_signed = false; };
+template <> struct PixelTraits<int32_t>  { using U = uint32_t; static constexpr int bits = 32; static constexpr bool is_signed = true;  };
+
+// Worst-case bits of one block: 12-bit header + 12 full-width values.
+template <typename T> constexpr int max_block_bits() { return 12 + kBlock * PixelTraits<T>::bits; }
+
+// ---- header code (Terse.hpp:517-535 encode, :361-372 decode) --------------------------------
+// Returns the header length in bits for width w following a block of width w_prev.
+__device__ __forceinline__ uint32_t header_len(uint32_t w, uint32_t w_prev) {
+    return w == w_prev ? 1u : (w < 7u ? 4u : (w < 10u ? 6u : 12u));
+}
+// Header value (LSB first, bit 0 = the "same" flag).
+__device__ __forceinline__ uint32_t header_val(uint32_t w, uint32_t w_prev) {
+    if (w == w_prev) return 1u;                              // Terse.hpp:518
+    if (w < 7u) return w << 1;                               // 0, then 3 bits     (:523)
+    if (w < 10u) return (7u + ((w - 7u) << 3)) << 1;         // 0, 111, 2 bits     (:527)
+    return (31u + ((w - 10u) << 5)) << 1;                    // 0, 111, 11, 6 bits (:531)
+}
+
+// Significant-bit width from the OR-reduction of a block (Terse.hpp:508-515, :551-560).
+// `m` is OR(v) for unsigned T and OR(|v|) for signed T, as an unsigned 32-bit magnitude.
+template <typename T>
+__device__ __forceinline__ uint32_t width_from_or(uint32_t m) {
+    uint32_t bl = 32u - (uint32_t)__builtin_clz(m | 0u) ;
+    bl = m ? bl : 0u;
+    if (PixelTraits<T>::is_signed) {
+        uint32_t w = m ? bl + 1u : 0u;
+        return w > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w;  // outside D3's domain
+    }
+    return bl;
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t magnitude(T v) {
+    if (PixelTraits<T>::is_signed) {
+        int32_t s = (int32_t)v;
+        return s < 0 ? 0u - (uint32_t)s : (uint32_t)s;       // |v| (Terse.hpp:514)
+    }
+    return (uint32_t)(typename PixelTraits<T>::U)v;
+}
+
+// ---- wavefront (64-lane) primitives ----------------------------------------------------------
+// Inclusive +scan across the 64 lanes with DPP row shifts / broadcasts (no LDS traffic).
+// Must be called with all 64 lanes active.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// Workgroup-wide exclusive scan of one u32 per thread (256 threads = 4 waves).
+// `wave_tot` is a 4-entry LDS array.  Returns the exclusive prefix; *total gets the tile sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane_id() == 63) wave_tot[wave_id()] = inc;
+    __syncthreads();
+    uint32_t t0 = wave_tot[0], t1 = wave_tot[1], t2 = wave_tot[2], t3 = wave_tot[3];
+    int w = wave_id();
+    uint32_t base = (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+    *total = t0 + t1 + t2 + t3;
+    return base + inc - v;
+}
+
+// ---- workspace layouts (device memory, carved by the host API) -------------------------------
+// encode: [status-shadow 64 B][frame_size u64 x F][tile_off u64 x F*T][tile_bits u32 x F*T]
+// decode: [tile_off u64 x F*T][widths u8 x F*nblocks (padded to 16)]
+__host__ __device__ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace trpx

@@ -1,0 +1,44 @@
+// Host-visible launcher interface between api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "codec_common.hpp"
+
+namespace trpx {
+
+struct EncodeArgs {
+    const void* pixels;        // device, [n_frames][n_values]
+    FrameGeom   geom;
+    uint32_t    n_frames;
+    uint8_t*    out;           // device, compact stack
+    size_t      out_capacity;
+    uint64_t*   frame_offsets; // device, n_frames + 1
+    uint32_t*   status;        // device, 8 words
+    // workspace carve
+    uint64_t*   frame_size;    // n_frames
+    uint64_t*   tile_off;      // n_frames * n_tiles
+    uint32_t*   tile_bits;     // n_frames * n_tiles
+};
+
+struct DecodeArgs {
+    const uint8_t*  terse;         // device
+    size_t          terse_bytes;
+    const uint64_t* frame_offsets; // device, n_frames + 1 (never null here: api fills it by a walk)
+    FrameGeom       geom;
+    uint32_t        n_frames;
+    void*           pixels_out;    // device
+    uint32_t*       status;        // device
+    // workspace carve
+    uint64_t*       tile_off;      // n_frames * n_tiles : bit offset of each tile inside its frame
+    uint8_t*        widths;        // n_frames * n_blocks : significant bits of every block
+    uint64_t*       walk_offsets;  // n_frames + 1 : frame offsets produced by the serial walk
+};
+
+hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
+hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
+hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
+hipError_t launch_synth(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
+                        void* out, hipStream_t st);
+
+}  // namespace trpx

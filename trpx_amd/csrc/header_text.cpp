@@ -1,0 +1,91 @@
+// Stream-serialise surface, host only: the ASCII header that precedes the raw stack in a .trpx
+// file.  trpx_header_format reproduces jpa::Terse::write byte for byte (reference
+// include/Terse.hpp:454-470: attribute order prolix_bits, signed, block, memory_size,
+// number_of_values, [dimensions], number_of_frames; `dimensions` only when set).
+// trpx_header_parse accepts what the reference reader accepts (Terse.hpp:485-498 over
+// XML_element.hpp:216-224, :296-307, :428-452): arbitrary bytes before "<Terse", attributes in
+// any order, either quote character, unknown attributes ignored.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/trpx_hip.h"
+
+extern "C" size_t trpx_header_format(const trpx_header* h, char* buf, size_t buf_cap) {
+    if (!h || !buf) return 0;
+    std::string s = "<Terse prolix_bits=\"" + std::to_string(h->prolix_bits) + "\"";
+    s += " signed=\"" + std::to_string(h->is_signed ? 1 : 0) + "\"";
+    s += " block=\"" + std::to_string(h->block) + "\"";
+    s += " memory_size=\"" + std::to_string((unsigned long long)h->memory_size) + "\"";
+    s += " number_of_values=\"" + std::to_string((unsigned long long)h->number_of_values) + "\"";
+    if (h->n_dims) {
+        s += " dimensions=\"";
+        for (unsigned i = 0; i < h->n_dims && i < 8; ++i) {
+            if (i) s += " ";
+            s += std::to_string((unsigned long long)h->dims[i]);
+        }
+        s += "\"";
+    }
+    s += " number_of_frames=\"" + std::to_string((unsigned long long)h->number_of_frames) + "\"/>";
+    if (s.size() + 1 > buf_cap) return 0;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return s.size();
+}
+
+static bool is_white(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+
+extern "C" int trpx_header_parse(const char* data, size_t len, trpx_header* h, size_t* payload_offset) {
+    if (!data || !h) return TRPX_ERR_INVALID_ARG;
+    static const char tag[] = "<Terse";
+    const size_t tl = sizeof(tag) - 1;
+    size_t p = 0;
+    bool found = false;
+    for (; p + tl < len; ++p)
+        if (data[p] == '<' && memcmp(data + p, tag, tl) == 0 && (is_white(data[p + tl]) || data[p + tl] == '/' || data[p + tl] == '>')) {
+            found = true;
+            break;
+        }
+    if (!found) return TRPX_ERR_CORRUPT;
+    size_t q = p + tl;
+    memset(h, 0, sizeof *h);
+    bool got_pb = false, got_sg = false, got_bl = false, got_ms = false, got_nv = false, got_nf = false;
+    while (q < len && data[q] != '>') {
+        if (is_white(data[q]) || data[q] == '/') { ++q; continue; }
+        size_t ns = q;
+        while (q < len && data[q] != '=' && data[q] != '>' && !is_white(data[q])) ++q;
+        std::string name(data + ns, q - ns);
+        while (q < len && is_white(data[q])) ++q;
+        if (q >= len || data[q] != '=') return TRPX_ERR_CORRUPT;
+        ++q;
+        while (q < len && is_white(data[q])) ++q;
+        if (q >= len) return TRPX_ERR_CORRUPT;
+        const char quote = data[q++];
+        size_t vs = q;
+        while (q < len && data[q] != quote) ++q;
+        if (q >= len) return TRPX_ERR_CORRUPT;
+        std::string val(data + vs, q - vs);
+        ++q;
+        char* end = nullptr;
+        if (name == "prolix_bits") { h->prolix_bits = (unsigned)strtoul(val.c_str(), &end, 10); got_pb = end != val.c_str(); }
+        else if (name == "signed") { h->is_signed = strtoul(val.c_str(), &end, 10) != 0; got_sg = end != val.c_str(); }
+        else if (name == "block") { h->block = (unsigned)strtoul(val.c_str(), &end, 10); got_bl = end != val.c_str(); }
+        else if (name == "memory_size") { h->memory_size = (uint64_t)strtold(val.c_str(), &end); got_ms = end != val.c_str(); }
+        else if (name == "number_of_values") { h->number_of_values = strtoull(val.c_str(), &end, 10); got_nv = end != val.c_str(); }
+        else if (name == "number_of_frames") { h->number_of_frames = strtoull(val.c_str(), &end, 10); got_nf = end != val.c_str(); }
+        else if (name == "dimensions") {
+            const char* s = val.c_str();
+            while (*s && h->n_dims < 8) {
+                unsigned long long d = strtoull(s, &end, 10);
+                if (end == s) break;
+                h->dims[h->n_dims++] = d;
+                s = end;
+            }
+        }
+    }
+    if (q >= len) return TRPX_ERR_CORRUPT;
+    // the reference's stoul/stoull/stold throw on a missing attribute
+    if (!(got_pb && got_sg && got_bl && got_ms && got_nv && got_nf)) return TRPX_ERR_CORRUPT;
+    if (payload_offset) *payload_offset = q + 1;
+    return TRPX_OK;
+}

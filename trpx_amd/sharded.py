@@ -1,0 +1,52 @@
+"""Frames shard across GPUs; the only exchange is the per-frame size gather (SURVEY.md 8 row e).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU
+tests).  Rank r owns the contiguous frame range [r*F/G, (r+1)*F/G) of the global stack
+(Terse.hpp:502-504: frames are independent and byte aligned, so the global stack is the
+concatenation of the ranks' local stacks).  The compressed payload never crosses xGMI: every rank
+keeps / writes its frames at the global byte offsets computed here.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def frame_range(n_frames_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous partition: GPU g <- frames [g*F/G, (g+1)*F/G)."""
+    return n_frames_total * rank // world, n_frames_total * (rank + 1) // world
+
+
+def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.Tensor | None = None,
+                          group=None):
+    """All-gather the per-frame sizes of every rank and prefix-sum them.
+
+    local_offsets: int64 [f_local + 1] (byte offsets of the local stack, as trpx_encode writes them).
+    Returns (global_offsets int64 [F_total + 1], my_base: 0-dim int64 tensor = first byte of this rank's
+    stack in the global stack, prolix_bits: max over ranks or None).  Works with ragged shards: sizes are
+    padded to the largest shard for the fixed-size collective."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sizes = local_offsets[1:] - local_offsets[:-1]
+    if world == 1:
+        pb = local_prolix_bits.max() if local_prolix_bits is not None else None
+        return local_offsets.clone(), torch.zeros((), dtype=torch.int64, device=local_offsets.device), pb
+    counts = torch.tensor([sizes.numel()], dtype=torch.int64, device=sizes.device)
+    all_counts = torch.empty(world, dtype=torch.int64, device=sizes.device)
+    dist.all_gather_into_tensor(all_counts, counts, group=group)
+    counts_host = [int(c) for c in all_counts.tolist()]
+    fmax = max(counts_host)
+    padded = torch.zeros(fmax + 1, dtype=torch.int64, device=sizes.device)
+    padded[: sizes.numel()] = sizes
+    if local_prolix_bits is not None:                       # fold the max-reduce into the same gather
+        padded[fmax] = local_prolix_bits.to(torch.int64).max()
+    gathered = torch.empty(world * (fmax + 1), dtype=torch.int64, device=sizes.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    gathered = gathered.view(world, fmax + 1)
+    parts = [gathered[r, : counts_host[r]] for r in range(world)]
+    all_sizes = torch.cat(parts)
+    global_offsets = torch.zeros(all_sizes.numel() + 1, dtype=torch.int64, device=sizes.device)
+    torch.cumsum(all_sizes, 0, out=global_offsets[1:])
+    my_base = global_offsets[sum(counts_host[:rank])]
+    pb = gathered[:, fmax].max() if local_prolix_bits is not None else None
+    return global_offsets, my_base, pb
