@@ -110,7 +110,9 @@ __global__ __launch_bounds__(kThreads) void k_tile_bits(const T* __restrict__ pi
     if (threadIdx.x == 0) {
         tile_bits[tile] = total;
         uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        if (m) atomicMax(&status[1], m);                    // d_prolix_bits (Terse.hpp:516)
+        // d_prolix_bits (Terse.hpp:516).  Read first: ~all tiles see a value that is already >= theirs,
+        // and 172k same-address atomics would serialise at the memory side (~11 ns each).
+        if (m > __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[1], m);
     }
 }
 
