@@ -38,7 +38,9 @@ typedef enum trpx_status {
     TRPX_ERR_CAPACITY = 3,      /* output or workspace too small                              */
     TRPX_ERR_HIP = 4,           /* a HIP runtime call failed (text has the HIP error)         */
     TRPX_ERR_CORRUPT = 5,       /* bitstream runs past its frame / buffer                     */
-    TRPX_ERR_NO_DEVICE = 6      /* no gfx950 device visible                                   */
+    TRPX_ERR_NO_DEVICE = 6,     /* no gfx950 device visible                                   */
+    TRPX_ERR_TIMEOUT = 7        /* single-pass encoder: a bounded inter-workgroup wait expired;
+                                   re-issue through the two-pass pipeline (trpx_set_encode_path) */
 } trpx_status;
 
 /* Pixel types = the reference CLI's dispatch set (src/terse.cpp:113-118). Odd = signed. */
@@ -79,8 +81,10 @@ size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, 
  *   status        DEVICE  uint32_t[TRPX_STATUS_WORDS] (see above); word 1 = prolix_bits
  *   workspace     DEVICE  >= trpx_encode_workspace_bytes(...), 16-byte aligned
  *
- * If the stack does not fit out_capacity nothing is written to `out`, frame_offsets is still
- * valid and status[0] = TRPX_ERR_CAPACITY (sizes-only query: pass out_capacity = 0).
+ * If the stack does not fit out_capacity, frame_offsets is still valid, status[0] =
+ * TRPX_ERR_CAPACITY and the contents of out[0 .. out_capacity) are unspecified (nothing beyond
+ * out_capacity is ever touched; sizes-only query: pass out = NULL, out_capacity = 0).
+ * Bytes [total, align_up(total, 4)) of `out` are zeroed (stores are dword granular).
  */
 int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block,
                 uint8_t* out, size_t out_capacity, uint64_t* frame_offsets, uint32_t* status,
@@ -134,10 +138,18 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
                     void* pixels_dev, void* stream);
 
 /*
+ * Encoder selection: 0 = auto (default: the single-pass look-back encoder whenever n_values % 4 == 0
+ * and `pixels` is 16-byte aligned, else the two-pass pipeline), 1 = always the two-pass pipeline.
+ * Process-wide; also settable with the environment variable TRPX_ENCODE_PATH=twopass.
+ */
+int trpx_set_encode_path(int path);
+
+/*
  * Per-kernel timing for bench.py's roofline leg.  While enabled (per calling thread), trpx_encode /
  * trpx_decode record a hipEvent on `stream` before their first and after each of their kernels;
  * trpx_profile_read waits for the last launch and returns the elapsed ms of each stage
- * (encode: tile_bits, frame_scan, stack_scan, zero_edges, pack; decode: walk, unpack).
+ * (single-pass encode: memset, encode_fused; two-pass encode: tile_bits, frame_scan, stack_scan,
+ * zero_edges, pack; decode: walk, unpack).
  * Returns the number of stages written.  Not graph-capturable while enabled.
  */
 int trpx_profile_enable(int on);

@@ -207,14 +207,37 @@ def test_capacity_error_and_sizes_only_query(gpu):
     import torch
     from trpx_amd import codec, _lib
     px = codec.synth(np.uint16, 0, 4, 512 * 512, device=gpu)
-    small = torch.full((1024,), 7, dtype=torch.uint8, device=gpu)
-    enc = codec.encode(px, out=small)
-    torch.cuda.synchronize()
-    assert int(enc.status[0].item()) == _lib.ERR_CAPACITY
-    assert bool((small == 7).all()), "nothing may be written when the stack does not fit"
     full = codec.encode(px)
     torch.cuda.synchronize()
-    assert torch.equal(full.frame_offsets, enc.frame_offsets), "sizes must still be reported"
+    for path in (0, 1):                                    # single-pass and two-pass encoders
+        _lib.lib().trpx_set_encode_path(path)
+        try:
+            big = torch.full((1 << 20,), 7, dtype=torch.uint8, device=gpu)
+            enc = codec.encode(px, out=big[:150000])        # room for one frame, not for four
+            torch.cuda.synchronize()
+            assert int(enc.status[0].item()) == _lib.ERR_CAPACITY
+            assert bool((big[150000:] == 7).all()), "nothing beyond out_capacity may ever be touched"
+            assert torch.equal(full.frame_offsets, enc.frame_offsets), "sizes must still be reported"
+        finally:
+            _lib.lib().trpx_set_encode_path(0)
+
+
+def test_single_pass_and_two_pass_encoders_agree(gpu):
+    import torch
+    from trpx_amd import codec, _lib
+    for dt, n, frames in ((np.uint16, 512 * 512, 24), (np.int32, 1000 * 1000, 3), (np.uint16, 12 * 1024 * 5 + 8, 7)):
+        px = codec.synth(dt, 3, frames, n, device=gpu)
+        a = codec.encode(px)
+        _lib.lib().trpx_set_encode_path(1)
+        try:
+            b = codec.encode(px)
+        finally:
+            _lib.lib().trpx_set_encode_path(0)
+        torch.cuda.synchronize()
+        a.check(); b.check()
+        assert torch.equal(a.frame_offsets, b.frame_offsets)
+        assert a.prolix_bits() == b.prolix_bits()
+        assert torch.equal(a.stack(), b.stack())
 
 
 def test_corrupt_and_truncated_streams_are_detected(gpu, oracle):

@@ -10,9 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrpx_hip.so")
+LIB_PATH = os.environ.get("TRPX_LIB") or os.path.join(_HERE, "libtrpx_hip.so")   # TRPX_LIB: kernel experiments only
 
-OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_CORRUPT, ERR_NO_DEVICE = range(7)
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_CORRUPT, ERR_NO_DEVICE, ERR_TIMEOUT = range(8)
 U8, I8, U16, I16, U32, I32 = range(6)
 STATUS_WORDS = 8
 
@@ -45,6 +45,7 @@ SYMBOLS = {
     "trpx_encode_host": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, C.POINTER(_SZ), _P, C.POINTER(_U), _I]),
     "trpx_decode_host": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _I]),
     "trpx_frame_offsets_host": (_I, [_P, _SZ, _SZ, _SZ, _U, _U, _P, _I]),
+    "trpx_set_encode_path": (_I, [_I]),
     "trpx_profile_enable": (_I, [_I]),
     "trpx_profile_read": (_I, [C.POINTER(C.c_float), _I]),
     "trpx_synth_fill": (_I, [_I, _U64, _U64, _SZ, _SZ, _P, _P]),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -46,16 +47,24 @@ bool geom_of(size_t n_values, unsigned block, trpx::FrameGeom* g) {
 }
 
 // workspace layouts ------------------------------------------------------------------------
-struct EncWs { size_t frame_size, tile_off, tile_bits, total; };
+struct EncWs { size_t frame_size, tile_off, tile_bits, fused, total; };
 EncWs enc_ws(const trpx::FrameGeom& g, size_t n_frames) {
     EncWs w;
     const size_t tiles = n_frames * (size_t)g.n_tiles;
     w.frame_size = 0;
     w.tile_off = trpx::align_up(w.frame_size + 8 * n_frames, 16);
     w.tile_bits = trpx::align_up(w.tile_off + 8 * tiles, 16);
-    w.total = trpx::align_up(w.tile_bits + 4 * tiles, 256);
+    w.fused = trpx::align_up(w.tile_bits + 4 * tiles, 256);          // descriptors of the single-pass encoder
+    w.total = w.fused + trpx::fused_workspace_bytes(g, n_frames);
     return w;
 }
+
+// 0 = auto (single-pass encoder when the frames are vector aligned), 1 = force the two-pass pipeline.
+// Initialised from $TRPX_ENCODE_PATH ("twopass" / "fused"), changed by trpx_set_encode_path().
+int g_encode_path = [] {
+    const char* e = getenv("TRPX_ENCODE_PATH");
+    return e && strcmp(e, "twopass") == 0 ? 1 : 0;
+}();
 struct DecWs { size_t walk_offsets, tile_off, widths, total; };
 DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     DecWs w;
@@ -138,7 +147,11 @@ int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames,
     a.frame_size = reinterpret_cast<uint64_t*>(ws + w.frame_size);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.tile_bits = reinterpret_cast<uint32_t*>(ws + w.tile_bits);
-    HIP_TRY(trpx::launch_encode(dtype, a, static_cast<hipStream_t>(stream)));
+    const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0;
+    if (g_encode_path == 0 && vec_ok)
+        HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
+    else
+        HIP_TRY(trpx::launch_encode(dtype, a, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }
 
@@ -175,6 +188,12 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
     HIP_TRY(trpx::launch_decode(out_dtype, a, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+int trpx_set_encode_path(int path) {
+    if (path != 0 && path != 1) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_encode_path: 0 = auto, 1 = two-pass");
+    g_encode_path = path;
     return TRPX_OK;
 }
 
@@ -230,6 +249,15 @@ int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_fr
     HIP_TRY(hipDeviceSynchronize());
     uint32_t st[TRPX_STATUS_WORDS];
     HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0] == TRPX_ERR_TIMEOUT && g_encode_path == 0) {   // never seen in practice; keeps the API total
+        g_encode_path = 1;
+        rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
+                         static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
+        g_encode_path = 0;
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    }
     if (st[0]) return fail((int)st[0], "trpx_encode_host: device status %u", st[0]);
     std::vector<uint64_t> offs(n_frames + 1);
     HIP_TRY(hipMemcpy(offs.data(), d_off.p, 8 * (n_frames + 1), hipMemcpyDeviceToHost));

@@ -1,0 +1,559 @@
+// Single-pass TERSE encoder for gfx950 (CDNA4): pixels are read from HBM exactly once and every
+// stream byte is written exactly once (algorithmic traffic N*sizeof(T) + S per frame).
+// Replaces jpa::Terse::f_compress (reference include/Terse.hpp:500-549) and the Bit_pointer.hpp
+// pack primitives (Bit_range::append_range :700-730, operator|= :628-649, Bit::set :490).
+//
+// Work decomposition
+//   tile      = 1024 consecutive codec blocks (12 288 values) of ONE frame, one 256-thread workgroup.
+//   sub-tile  = 256 blocks; lane `tid` owns block (r*256 + tid) of sub-tile r = 0..3, so every
+//               wave-level load covers 1536 contiguous bytes (u16).
+//   The serial bit cursor of the reference (Terse.hpp:504) becomes three prefix sums:
+//     lanes -> wavefront DPP scan, wavefronts/sub-tiles -> LDS, tiles -> decoupled look-back
+//     through 8-byte descriptors in HBM (agent-scope relaxed atomics, the data is the flag):
+//       tile chain  (inside a frame)   : bits  -> exclusive bit offset of the tile in its frame
+//       frame chain (across the stack) : bytes -> S_f = 1 + bits/8 (Terse.hpp:547) -> frame base
+//   Packing: every lane serialises its block with code specialised on the block's width W (all
+//   shifts static), ORs it into the workgroup's LDS staging image at its scanned bit offset; the
+//   image is flushed to HBM in whole dwords (coalesced), 4 rounds per tile with two staging
+//   buffers (one barrier per round).  A dword shared by two tiles is completed by the later tile
+//   with the earlier tile's tail bits handed over through a third descriptor ("tail" chain), so
+//   the output needs no pre-zeroing and no global atomics.
+//
+// Forward progress: tile i only ever waits for tiles < i.  Tiles are taken in blockIdx order,
+// which the hardware dispatches in order; every wait is bounded and raises status[0] =
+// TRPX_ERR_HIP-class timeout (7) instead of hanging, in which case the host API re-runs the
+// stack through the two-pass pipeline (encode.hip).
+#include "codec_common.hpp"
+#include "encode_kernels.hpp"
+#include "profile.hpp"
+#include <stdlib.h>
+
+namespace trpx {
+
+// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels, 2 (512 blocks) for 32-bit pixels, so that the
+// worst-case LDS image of a whole tile stays ~26 KB (6 workgroups per CU)
+template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
+constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seconds), then give up
+
+constexpr uint64_t kStInvalid = 0, kStAgg = 1, kStPrefix = 2;
+__device__ __forceinline__ uint64_t make_desc(uint64_t st, uint64_t v) { return (st << 62) | (v & ((1ull << 62) - 1)); }
+__device__ __forceinline__ uint64_t desc_status(uint64_t d) { return d >> 62; }
+__device__ __forceinline__ uint64_t desc_value(uint64_t d) { return d & ((1ull << 62) - 1); }
+
+__device__ __forceinline__ uint64_t ld_desc(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_desc(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+// Decoupled look-back by one full wavefront: sum of the values of desc[lo .. idx-1], using the
+// nearest PREFIX descriptor as a shortcut.  Returns false on timeout.
+__device__ bool lookback(const uint64_t* __restrict__ desc, int64_t idx, int64_t lo, uint64_t* result) {
+    const int lane = lane_id();
+    uint64_t acc = 0;
+    int64_t pos = idx - 1;
+    while (pos >= lo) {
+        const int64_t my = pos - lane;
+        const bool in = my >= lo;
+        uint64_t g = 0;
+        uint32_t first_p = 64;
+        uint32_t spins = 0;
+        for (;;) {
+            g = in ? ld_desc(desc + my) : make_desc(kStPrefix, 0);   // below `lo`: prefix 0 ends the chain
+            const uint64_t pmask = __ballot(desc_status(g) == kStPrefix);
+            const uint64_t imask = __ballot(desc_status(g) == kStInvalid);
+            first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+            const uint64_t need = first_p >= 63u ? ~0ull : ((2ull << first_p) - 1ull);
+            if ((imask & need) == 0) break;
+            if (++spins > kSpinLimit) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        acc += wave_sum64((uint32_t)lane <= first_p ? desc_value(g) : 0ull);
+        if (first_p < 64u) break;
+        pos -= 64;
+    }
+    *result = acc;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A codec block (12 values) lives in registers as the raw little-endian dwords it was loaded as:
+// 3 dwords for 8-bit, 6 for 16-bit, 12 for 32-bit pixels.  Field k is a static bit-field extract.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Raw {
+    static constexpr int bits = PixelTraits<T>::bits;
+    static constexpr int per = 32 / bits;                 // values per dword
+    static constexpr int dw = kBlock / per;               // dwords per block
+};
+
+template <typename T>
+__device__ __forceinline__ uint32_t raw_field(const uint32_t (&raw)[Raw<T>::dw], int k) {   // zero-extended value k
+    constexpr int per = Raw<T>::per, bits = Raw<T>::bits;
+    const uint32_t x = raw[k / per] >> ((k % per) * bits);
+    return bits == 32 ? x : x & ((1u << (bits & 31)) - 1u);
+}
+
+template <typename T> struct QuadVec;
+template <> struct QuadVec<uint8_t>  { typedef uint32_t type; };
+template <> struct QuadVec<int8_t>   { typedef uint32_t type; };
+template <> struct QuadVec<uint16_t> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct QuadVec<int16_t>  { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct QuadVec<uint32_t> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct QuadVec<int32_t>  { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+
+// A full, vector-aligned block; streamed once -> non-temporal loads (3 x 4 values).
+template <typename T>
+__device__ __forceinline__ void load_raw_nt(const T* __restrict__ p, uint32_t (&raw)[Raw<T>::dw]) {
+    using V = typename QuadVec<T>::type;
+    constexpr int q = Raw<T>::dw / 3;
+    const V* src = reinterpret_cast<const V*>(p);
+    union U { V vec; uint32_t x[q]; };
+    U a, b, c;
+    a.vec = __builtin_nontemporal_load(src);
+    b.vec = __builtin_nontemporal_load(src + 1);
+    c.vec = __builtin_nontemporal_load(src + 2);
+#pragma unroll
+    for (int i = 0; i < q; ++i) { raw[i] = a.x[i]; raw[q + i] = b.x[i]; raw[2 * q + i] = c.x[i]; }
+}
+// The frame's last (partial) block: element loads, missing values read as zero.
+template <typename T>
+__device__ __forceinline__ void load_raw_partial(const T* __restrict__ p, int nb, uint32_t (&raw)[Raw<T>::dw]) {
+    using UT = typename PixelTraits<T>::U;
+#pragma unroll
+    for (int i = 0; i < Raw<T>::dw; ++i) raw[i] = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k)
+        if (k < nb) raw[k / Raw<T>::per] |= (uint32_t)(UT)p[k] << ((k % Raw<T>::per) * Raw<T>::bits);
+}
+
+// OR-scan + bit length (Terse.hpp:508-515, :551-560) on the raw dwords.
+template <typename T>
+__device__ __forceinline__ uint32_t raw_width(const uint32_t (&raw)[Raw<T>::dw]) {
+    constexpr int bits = Raw<T>::bits;
+    uint32_t m = 0;
+    if (!PixelTraits<T>::is_signed) {
+#pragma unroll
+        for (int i = 0; i < Raw<T>::dw; ++i) m |= raw[i];
+        if (bits == 16) m = (m | (m >> 16)) & 0xFFFFu;
+        if (bits == 8) { m |= m >> 16; m = (m | (m >> 8)) & 0xFFu; }
+    } else if (bits == 32) {
+#pragma unroll
+        for (int i = 0; i < Raw<T>::dw; ++i) { const int32_t x = (int32_t)raw[i]; m |= (uint32_t)(x < 0 ? -x : x); }
+    } else if (bits == 16) {
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < Raw<T>::dw; ++i) {                          // packed |x| = max(x, -x) (wraps for -32768)
+            union { uint32_t u; s2 v; } x, y;
+            x.u = raw[i];
+            y.v = __builtin_elementwise_max(x.v, (s2)(-x.v));
+            acc |= y.u;
+        }
+        m = (acc | (acc >> 16)) & 0xFFFFu;                              // |−32768| reads 0x8000: bitlen 16 -> clamped below
+    } else {
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) {
+            const int32_t x = (int32_t)(int8_t)(raw[k / 4] >> ((k % 4) * 8));
+            m |= (uint32_t)(x < 0 ? -x : x);
+        }
+    }
+    return width_from_or<T>(m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Width-specialised block serialiser.
+// ---------------------------------------------------------------------------------------------
+// OR an ND-dword little-endian bit string (exactly 12*W valid bits, rest zero) into the LDS image
+// at bit position `pos`.  First / last touched dwords may be shared with other lanes.
+template <int ND>
+__device__ __forceinline__ void lds_or_string(uint32_t* __restrict__ stage, uint32_t pos, const uint32_t (&p)[ND]) {
+    const uint32_t d = pos >> 5, s = pos & 31u, rs = 32u - s;
+    uint32_t prev = 0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const uint32_t x = (uint32_t)((((uint64_t)p[j] << 32) | prev) >> rs);   // (p[j] << s) | (prev >> (32-s))
+        if (j == 0 || j >= ND - 1) atomicOr(&stage[d + j], x);
+        else stage[d + j] = x;                              // interior dword: owned by this block alone
+        prev = p[j];
+    }
+    const uint32_t x = (uint32_t)(((uint64_t)prev << 32) >> rs >> 32);          // prev >> (32-s), 0 when s == 0
+    if (x) atomicOr(&stage[d + ND], x);
+}
+
+template <typename T, int W>
+__device__ __forceinline__ void pack_payload_w(uint32_t* __restrict__ stage, uint32_t pos,
+                                               const uint32_t (&raw)[Raw<T>::dw]) {
+    constexpr int NB = kBlock * W;
+    constexpr int ND = (NB + 31) / 32;
+    constexpr int per = Raw<T>::per, bits = Raw<T>::bits;
+    constexpr uint32_t MASK = W >= 32 ? 0xFFFFFFFFu : ((1u << (W & 31)) - 1u);
+    uint32_t p[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) p[j] = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k) {
+        const uint32_t u = (raw[k / per] >> ((k % per) * bits)) & MASK;   // value mod 2^W (Bit_pointer.hpp:707-710)
+        const int bit = k * W;
+        p[bit >> 5] |= u << (bit & 31);
+        if ((bit & 31) + W > 32) p[(bit >> 5) + 1] |= u >> (32 - (bit & 31));
+    }
+    lds_or_string<ND>(stage, pos, p);
+}
+
+// Binary dispatch on a wave-uniform width (scalar compares only, one specialised body executes).
+template <typename T, int LO, int HI>
+struct PackDispatch {
+    static __device__ __forceinline__ void run(uint32_t* stage, uint32_t pos, uint32_t w0,
+                                               const uint32_t (&raw)[Raw<T>::dw]) {
+        if constexpr (LO == HI) pack_payload_w<T, LO>(stage, pos, raw);
+        else {
+            constexpr int MID = (LO + HI) / 2;
+            if (w0 <= (uint32_t)MID) PackDispatch<T, LO, MID>::run(stage, pos, w0, raw);
+            else PackDispatch<T, MID + 1, HI>::run(stage, pos, w0, raw);
+        }
+    }
+};
+
+// Generic (runtime width, partial block) serialiser: only the last block of a frame uses it.
+template <typename T>
+__device__ __forceinline__ void pack_payload_generic(uint32_t* __restrict__ stage, uint32_t pos, uint32_t w, int nb,
+                                                     const uint32_t (&raw)[Raw<T>::dw]) {
+    const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k) {
+        if (k < nb) {
+            const uint64_t x = (uint64_t)(raw_field<T>(raw, k) & mask) << (pos & 31u);
+            if ((uint32_t)x) atomicOr(&stage[pos >> 5], (uint32_t)x);
+            if ((uint32_t)(x >> 32)) atomicOr(&stage[(pos >> 5) + 1], (uint32_t)(x >> 32));
+            pos += w;
+        }
+    }
+}
+
+template <typename T>
+constexpr int fused_stage_dwords() { return sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 8; }   // worst-case tile
+
+struct FusedArgs {
+    FrameGeom g;
+    uint32_t n_frames;
+    uint32_t tiles_per_frame;      // ceil(n_blocks / (sub_tiles * 256))
+    uint64_t out_capacity;
+    uint64_t* tile_desc;           // [F * tpf]  AGG: tile bits, PREFIX: inclusive bits inside the frame
+    uint64_t* tail_desc;           // [F * tpf]  READY(1): partial last dword of the tile
+    uint64_t* frame_desc;          // [F]        AGG: S_f bytes, PREFIX: inclusive bytes
+    uint64_t* frame_offsets;       // [F + 1]    output
+    uint32_t* out32;
+    uint32_t* status;
+    uint32_t debug;                // timing experiments only: 1 = no look-back waits, 2 = no tail wait (output invalid),
+                                   // 4 = write s_memrealtime stamps (diagnostic build of the run, never timed)
+    uint64_t* stamps;              // [tiles][8]
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restrict__ pixels, FusedArgs a) {
+    constexpr int kSub = sub_tiles<T>();
+    constexpr int kFusedTileBlocks = kSub * kThreads;
+    constexpr int kStage = fused_stage_dwords<T>();
+    __shared__ uint32_t s_stage[kStage];
+    __shared__ uint32_t s_wtot[kSub * 4];   // bits of each (round, wave) piece without its lane-0 header
+    __shared__ uint32_t s_wfl[kSub * 4];    // first width | last width << 8 | lane 0 valid << 16
+    __shared__ uint64_t s_excl_bits;       // bits of this frame before the tile
+    __shared__ uint64_t s_base_bytes;      // first byte of this frame in the stack
+    __shared__ uint32_t s_abort;
+
+    const uint32_t tid = threadIdx.x;
+#define TRPX_STAMP(slot) do { if ((a.debug & 4u) && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    TRPX_STAMP(0);
+    const int lane = lane_id(), wave = wave_id();
+    const FrameGeom g = a.g;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t frame = (uint32_t)(tile / a.tiles_per_frame);
+    const uint32_t t = (uint32_t)(tile % a.tiles_per_frame);
+    const bool last_tile_of_frame = t + 1 == a.tiles_per_frame;
+    const T* fp = pixels + (uint64_t)frame * g.n_values;
+    const uint32_t b0 = t * kFusedTileBlocks;
+
+    if (tid == 0) s_abort = 0;
+    for (int i = tid; i < kStage; i += kThreads) s_stage[i] = 0u;
+
+    // ---- load, widths, header / payload lengths ------------------------------------------------
+    uint32_t v[kSub][Raw<T>::dw];
+    uint32_t w[kSub], up[kSub], len[kSub], inc[kSub];
+    int nb[kSub];
+#pragma unroll
+    for (int r = 0; r < kSub; ++r) {
+        const uint32_t b = b0 + r * kThreads + tid;
+        const uint64_t first = (uint64_t)b * kBlock;
+        nb[r] = 0;
+        if (b < g.n_blocks) {
+            if (first + kBlock <= g.n_values) { load_raw_nt<T>(fp + first, v[r]); nb[r] = kBlock; }
+            else { nb[r] = (int)(g.n_values - first); load_raw_partial<T>(fp + first, nb[r], v[r]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < Raw<T>::dw; ++i) v[r][i] = 0u;
+        }
+    }
+    // width of the block before the tile's first block (w_{-1} = 0 at frame start, Terse.hpp:505)
+    uint32_t tile_halo = 0;
+    if (lane == 0 && b0 > 0) {                                           // every wave: it redoes the piece scan itself
+        uint32_t h[Raw<T>::dw];
+        load_raw_nt<T>(fp + (uint64_t)(b0 - 1) * kBlock, h);            // block b0-1 is never the frame's last: full
+        tile_halo = raw_width<T>(h);
+    }
+    // Lanes 1..63 get the previous block's width from their neighbour; lane 0's header depends on the
+    // previous wavefront's last width, so it is left out of the scan here and added after barrier #1.
+    uint32_t wmax = 0;
+#pragma unroll
+    for (int r = 0; r < kSub; ++r) {
+        w[r] = nb[r] ? raw_width<T>(v[r]) : 0u;
+        wmax = w[r] > wmax ? w[r] : wmax;
+        up[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[r], 0x138, 0xf, 0xf, false);   // wave_shr:1
+        len[r] = nb[r] ? (lane ? header_len(w[r], up[r]) : 0u) + (uint32_t)nb[r] * w[r] : 0u;
+        inc[r] = wave_inclusive_scan(len[r]);
+        const uint32_t w_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[r]);
+        const uint32_t v_first = (uint32_t)__builtin_amdgcn_readfirstlane(nb[r]);
+        if (lane == 63) {
+            s_wtot[r * 4 + wave] = inc[r];
+            s_wfl[r * 4 + wave] = w_first | (w[r] << 8) | ((v_first ? 1u : 0u) << 16);
+        }
+    }
+    wmax = wave_max(wmax);
+    __syncthreads();                                                     // #1: wave totals + staging zeroed
+    TRPX_STAMP(1);
+
+    // Every wave, lanes 0..15: lane-0 header of each of the 16 (round, wave) pieces -- it depends on the
+    // previous piece's last width -- then the exclusive scan of the piece sizes (tile-relative bit offsets).
+    uint32_t rb[kSub + 1];               // tile-relative bit where round r starts; rb[kSub] = tile bits
+    uint32_t off[kSub], wp[kSub];        // tile-relative bit position of this lane's block; its w_{b-1}
+    {
+        uint32_t tot = 0, h0 = 0, wprev = 0;
+        if (lane < kSub * 4) {
+            const uint32_t wfl = s_wfl[lane];
+            wprev = lane == 0 ? tile_halo : (s_wfl[lane - 1] >> 8) & 0xFFu;
+            h0 = (wfl >> 16) & 1u ? header_len(wfl & 0xFFu, wprev) : 0u;
+            tot = s_wtot[lane] + h0;
+        }
+        const uint32_t incl = wave_inclusive_scan(tot);
+        const uint32_t excl = incl - tot;
+        const uint32_t hw = h0 | (wprev << 8);
+#pragma unroll
+        for (int r = 0; r < kSub; ++r) {
+            rb[r] = (uint32_t)__builtin_amdgcn_readlane((int)excl, r * 4);
+            const uint32_t pb = (uint32_t)__shfl((int)excl, r * 4 + wave, 64);
+            const uint32_t ph = (uint32_t)__shfl((int)hw, r * 4 + wave, 64);
+            off[r] = pb + (lane ? (ph & 0xFFu) : 0u) + inc[r] - len[r];
+            wp[r] = lane ? up[r] : ph >> 8;
+        }
+        rb[kSub] = (uint32_t)__builtin_amdgcn_readlane((int)incl, kSub * 4 - 1);
+    }
+    const uint32_t tile_total = rb[kSub];
+
+    // publish this tile's bit count at once (decoupled look-back: nobody waits for our look-back)
+    if (tid == 0 && !(a.debug & 1u))
+        st_desc(a.tile_desc + tile, make_desc(t == 0 ? kStPrefix : kStAgg, tile_total));
+    // d_prolix_bits (Terse.hpp:516): read first, ~every wave sees a value that is already >= its own
+    if (wmax && lane == 0 && wmax > __hip_atomic_load(&a.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&a.status[1], wmax);
+
+    // The frame's LAST tile looks back before it packs: every tile of the next frame waits for the S_f it
+    // publishes.  All other tiles pack first (their look-back is then usually satisfied at the first poll).
+    uint64_t early_excl = 0;
+    bool early_ok = true;
+    if (last_tile_of_frame && wave == 0 && t != 0 && !(a.debug & 1u)) {
+        early_ok = lookback(a.tile_desc, (int64_t)tile, (int64_t)(tile - t), &early_excl);
+        if (early_ok && lane == 0) {
+            st_desc(a.tile_desc + tile, make_desc(kStPrefix, early_excl + tile_total));
+            st_desc(a.frame_desc + frame, make_desc(kStAgg, 1 + (early_excl + tile_total) / 8));   // S_f (Terse.hpp:547)
+        }
+    }
+
+    // ---- pack into the tile-relative LDS image, look back meanwhile, flush with a funnel shift ---------
+    {
+#pragma unroll
+        for (int r = 0; r < kSub; ++r) {
+            const uint32_t pos = off[r];
+            const uint32_t hl = header_len(w[r], wp[r]);
+#ifndef TRPX_ABLATE
+#define TRPX_ABLATE 0
+#endif
+            if (nb[r] && !(TRPX_ABLATE & 2)) {
+                const uint64_t hx = (uint64_t)header_val(w[r], wp[r]) << (pos & 31u);
+                atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
+                if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
+                if (w[r] && nb[r] != kBlock) pack_payload_generic<T>(s_stage, pos + hl, w[r], nb[r], v[r]);
+            }
+            // full blocks: one pass per distinct width present in the wavefront, each with static shifts
+            uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(nb[r] == kBlock && w[r] != 0u);
+            while (todo) {
+                const int l0 = __builtin_ctzll(todo);
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w[r], l0);
+                const bool mine = nb[r] == kBlock && w[r] == w0;
+#pragma unroll
+                for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));   // keep the bodies out of LICM's reach
+                if (mine) PackDispatch<T, 1, PixelTraits<T>::bits>::run(s_stage, pos + hl, w0, v[r]);
+                todo &= ~__ballot(mine);
+            }
+        }
+
+        // cross-tile prefixes (decoupled look-back), after this wave's share of the packing
+        if (wave == 0) {
+            uint64_t excl = 0;
+            bool ok = true;
+            if (a.debug & 1u) excl = (uint64_t)t * 40000u;
+            else if (last_tile_of_frame) {
+                excl = early_excl;
+                ok = early_ok;
+                if (t == 0 && lane == 0)                                  // single-tile frame
+                    st_desc(a.frame_desc + frame, make_desc(kStAgg, 1 + (uint64_t)tile_total / 8));
+            } else if (t != 0) {
+                ok = lookback(a.tile_desc, (int64_t)tile, (int64_t)(tile - t), &excl);
+                if (ok && lane == 0) st_desc(a.tile_desc + tile, make_desc(kStPrefix, excl + tile_total));
+            }
+            if (lane == 0) { s_excl_bits = excl; if (!ok) s_abort = 1; }
+            TRPX_STAMP(2);
+        } else if (wave == 1) {
+            uint64_t base = 0;
+            bool ok = true;
+            if (a.debug & 1u) base = (uint64_t)frame * 120000u;
+            else ok = lookback(a.frame_desc, (int64_t)frame, 0, &base);
+            if (lane == 0) { s_base_bytes = base; if (!ok) s_abort = 1; }
+        }
+    }
+    __syncthreads();                                                     // #2: tile packed, prefixes known
+    TRPX_STAMP(3);
+    const bool aborted = s_abort != 0;
+    const uint64_t excl_bits = s_excl_bits, base_bytes = s_base_bytes;
+    const uint64_t frame_size = 1 + (excl_bits + tile_total) / 8;        // valid for the frame's last tile
+    if (last_tile_of_frame && tid == 0 && !aborted) {
+        st_desc(a.frame_desc + frame, make_desc(kStPrefix, base_bytes + frame_size));
+        a.frame_offsets[frame + 1] = base_bytes + frame_size;
+        if (frame == 0) a.frame_offsets[0] = 0;
+        if (frame + 1 == a.n_frames && align_up(base_bytes + frame_size, 4) > a.out_capacity)
+            atomicMax(&a.status[0], 3u);                                 // TRPX_ERR_CAPACITY
+    }
+    if (aborted) {
+        if (tid == 0) atomicMax(&a.status[0], 7u);                       // look-back timeout
+        return;
+    }
+    const uint64_t p0 = 8 * base_bytes + excl_bits;                      // absolute bit of the tile's first bit
+    // bits this tile must materialise: its blocks, plus the frame's pad up to the byte S_f
+    const uint64_t p_end = last_tile_of_frame ? 8 * (base_bytes + frame_size) : p0 + tile_total;
+    const bool writable = align_up((p_end + 7) / 8, 4) <= a.out_capacity;   // sizes-only query / too small: no stores
+    const uint32_t s0 = (uint32_t)(p0 & 31), sh = (32u - s0) & 31u;
+    const bool head_pending = s0 != 0;                                   // first dword also holds the previous tile's bits
+    const uint64_t d_first = p0 >> 5, d_last = p_end >> 5;
+
+    // ---- flush: global dword d_first + j = {image[k+1], image[k]} >> sh, k = j - (s0 != 0) -------------------
+    const int32_t k_first = head_pending ? -1 : 0;
+    const uint32_t n_out = (uint32_t)(d_last - d_first);
+    uint32_t head_keep = 0;
+    for (uint32_t j = tid; j < ((TRPX_ABLATE & 4) ? 0u : n_out); j += kThreads) {
+        const int32_t k = k_first + (int32_t)j;
+        const uint32_t lo = k >= 0 ? s_stage[k] : 0u, hi = s_stage[k + 1];
+        const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, sh);
+        if (j == 0 && head_pending) head_keep = x;                       // completed below with the previous tile's tail
+        else if (writable) __builtin_nontemporal_store(x, a.out32 + d_first + j);
+    }
+
+    // ---- tile boundary dwords: tail hand-over ----------------------------------------------------------
+    if (tid == 0) {
+        const bool is_last_tile = tile + 1 == (uint64_t)a.n_frames * a.tiles_per_frame;
+        const int32_t kt = k_first + (int32_t)n_out;
+        const uint32_t tail_bits = (p_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], kt >= 0 ? s_stage[kt] : 0u, sh) : 0u;
+        const bool completed_first = d_last > d_first;                   // tile finished at least its first dword
+        // Publish the tail FIRST whenever it does not depend on the predecessor's: the hand-over is then
+        // never a serial chain through the tiles.
+        if (completed_first) {
+            if (is_last_tile) { if ((p_end & 31) != 0 && writable) __builtin_nontemporal_store(tail_bits, a.out32 + d_last); }
+            else st_desc(a.tail_desc + tile, make_desc(kStAgg, tail_bits));
+        }
+        TRPX_STAMP(4);
+        uint32_t pred_tail = 0;
+        bool ok = true;
+        if (head_pending && !(a.debug & 2u)) {                           // wait for tile-1's tail bits
+            uint32_t spins = 0;
+            uint64_t gd;
+            while (desc_status(gd = ld_desc(a.tail_desc + tile - 1)) == kStInvalid) {
+                if (++spins > kSpinLimit) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            pred_tail = (uint32_t)desc_value(gd);
+        }
+        if (!ok) atomicMax(&a.status[0], 7u);
+        TRPX_STAMP(5);
+        if (a.debug & 4u) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[blockIdx.x * 8 + 6] = xcc; }
+        if (completed_first) {
+            if (head_pending && writable) __builtin_nontemporal_store(head_keep | pred_tail, a.out32 + d_first);
+        } else {                                                         // whole tile inside one dword (tiny frames)
+            const uint32_t my_tail = tail_bits | pred_tail;
+            if (is_last_tile) { if ((p_end & 31) != 0 && writable) __builtin_nontemporal_store(my_tail, a.out32 + d_last); }
+            else st_desc(a.tail_desc + tile, make_desc(kStAgg, my_tail));
+        }
+    }
+}
+
+template <typename T>
+static uint32_t fused_tiles_per_frame(const FrameGeom& g) {
+    constexpr uint32_t tb = sub_tiles<T>() * kThreads;
+    return (g.n_blocks + tb - 1) / tb;
+}
+
+size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames) {
+    const size_t tpf = ((size_t)g.n_blocks + 2 * kThreads - 1) / (2 * kThreads);   // finest tiling (32-bit pixels)
+    return align_up(8 * (2 * n_frames * tpf + n_frames), 256) + 64 * n_frames * tpf;   // + diagnostic stamps
+}
+
+template <typename T>
+static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) {
+    FusedArgs a;
+    a.g = e.geom;
+    a.n_frames = e.n_frames;
+    a.tiles_per_frame = fused_tiles_per_frame<T>(e.geom);
+    a.out_capacity = e.out_capacity;
+    const size_t tiles = (size_t)e.n_frames * a.tiles_per_frame;
+    a.tile_desc = static_cast<uint64_t*>(ws);
+    a.tail_desc = a.tile_desc + tiles;
+    a.frame_desc = a.tail_desc + tiles;
+    a.frame_offsets = e.frame_offsets;
+    a.out32 = reinterpret_cast<uint32_t*>(e.out);
+    a.status = e.status;
+    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (2 * tiles + e.n_frames), 256));
+    a.debug = getenv("TRPX_FUSED_DEBUG") ? (uint32_t)atoi(getenv("TRPX_FUSED_DEBUG")) : 0u;
+    Profiler& prof = profiler();
+    prof.begin();
+    prof.mark(st);
+    hipError_t err = hipMemsetAsync(e.status, 0, sizeof(uint32_t) * 8, st);
+    if (err != hipSuccess) return err;
+    err = hipMemsetAsync(ws, 0, 8 * (2 * tiles + e.n_frames), st);      // every polled word, every call
+    if (err != hipSuccess) return err;
+    prof.mark(st);
+    hipLaunchKernelGGL((k_encode_fused<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, st,
+                       static_cast<const T*>(e.pixels), a);
+    prof.mark(st);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_fused(int dtype, const EncodeArgs& e, void* ws, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_fused_t<uint8_t>(e, ws, st);
+    case 1: return launch_fused_t<int8_t>(e, ws, st);
+    case 2: return launch_fused_t<uint16_t>(e, ws, st);
+    case 3: return launch_fused_t<int16_t>(e, ws, st);
+    case 4: return launch_fused_t<uint32_t>(e, ws, st);
+    case 5: return launch_fused_t<int32_t>(e, ws, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace trpx

@@ -36,6 +36,9 @@ struct DecodeArgs {
 };
 
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
+// single-pass encoder (encode_fused.hip); `ws` = fused_workspace_bytes() of descriptor words
+size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames);
+hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStream_t st);
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 hipError_t launch_synth(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
