@@ -187,7 +187,12 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
-    HIP_TRY(trpx::launch_decode(out_dtype, a, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
+    static const bool basic = getenv("TRPX_DECODE_PATH") && strcmp(getenv("TRPX_DECODE_PATH"), "basic") == 0;
+    const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
+    if (frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0)
+        HIP_TRY(trpx::launch_decode_fast(out_dtype, a, static_cast<hipStream_t>(stream)));
+    else
+        HIP_TRY(trpx::launch_decode(out_dtype, a, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }
 

@@ -1,0 +1,348 @@
+// PROLIX decode, tuned kernels for gfx950 (CDNA4).  Replaces jpa::Terse::prolix(Iterator, frame)
+// (reference include/Terse.hpp:352-389) and Bit_range::get_range / operator T()
+// (Bit_pointer.hpp:742-792, :597-617).  Same two stages as decode.hip, restructured:
+//
+//   k_walk_lds      one wavefront per frame walks the header chain (Terse.hpp:360-372) with the
+//                   frame's stream staged through LDS in 16 KB chunks: a step costs an LDS round
+//                   trip instead of an L2/HBM one.  64 candidate blocks are tested per step, so a run
+//                   of equal-width blocks is one step.  Emits width[b] (u8) and the bit offset of
+//                   every 256-block group.
+//   k_unpack_tiles  tile = 1024 blocks (512 for 32-bit pixels), 4 (2) blocks per lane.  widths ->
+//                   lengths -> wave/LDS scan -> the tile's stream bytes are fetched once, coalesced,
+//                   into LDS -> every lane extracts its 12 fields with code specialised on the block
+//                   width (static shifts, v_bfe) -> 24/48-byte streaming stores.
+//
+// HBM traffic per frame: S (stream, read twice: walk + unpack) + n_blocks (widths, written+read)
+// + N*sizeof(T) (pixels, written once).  Algorithmic bytes: S + N*sizeof(T).
+#include "codec_common.hpp"
+#include "encode_kernels.hpp"
+#include "profile.hpp"
+
+namespace trpx {
+
+// ---------------------------------------------------------------------------------------------
+// k_walk_lds
+// ---------------------------------------------------------------------------------------------
+constexpr int kWalkChunkDw = 4096;                    // 16 KB of stream per LDS refill
+
+__global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                    const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                    uint32_t max_w, uint8_t* __restrict__ widths,
+                                                    uint64_t* __restrict__ tile_off, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_chunk[kWalkChunkDw + 4];
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint64_t frame = blockIdx.x;
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    if (!(fe > fo && fe <= terse_bytes)) {
+        if (lane == 0) atomicMax(&status[0], 5u);
+        return;
+    }
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(terse);
+    const uint64_t n_dw = (terse_bytes + 3) / 4;
+    const bool base16 = ((uintptr_t)terse & 15) == 0;
+    const uint64_t frame_abit = 8 * fo, limit_bits = 8 * (fe - fo);
+    uint8_t* __restrict__ wf = widths + frame * g.n_blocks;
+    uint64_t* __restrict__ tf = tile_off + frame * g.n_tiles;
+    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);
+
+    // All positions are frame-relative bit offsets in 32 bits (the launcher routes frames of >= 2^32 bits
+    // to the basic path); everything that steers the loop is wave-uniform and lives in SGPRs.
+    const uint32_t limit = (uint32_t)limit_bits;
+    const uint64_t frame_dw = frame_abit >> 5;        // absolute dword of the frame's first bit
+    const uint32_t frame_sh = (uint32_t)(frame_abit & 31);
+    int32_t c_lo = 0, c_hi = 0;                       // frame-relative dword range [c_lo, c_hi) held in s_chunk
+                                                      // (c_lo may be -1..-3: chunks start on absolute 16-byte boundaries)
+    uint32_t b = 0, w_prev = 0, pos = 0, final_pos = 0;
+    bool bad = false;
+    while (b < g.n_blocks) {
+        const uint32_t stride = 1u + kBlock * w_prev;
+        // dwords needed this step: candidates pos .. pos + 63*stride, each peeking 2 dwords
+        const uint32_t need_lo = (frame_sh + pos) >> 5;
+        const uint32_t need_hi = ((frame_sh + pos + 63u * stride) >> 5) + 2;
+        if ((int32_t)need_lo < c_lo || (int32_t)need_hi > c_hi) {   // refill (wave-uniform), 16-byte coalesced
+            c_lo = (int32_t)(((frame_dw + need_lo) & ~3ull) - frame_dw);
+            c_hi = c_lo + kWalkChunkDw;
+            const uint64_t d0 = (uint64_t)((int64_t)frame_dw + c_lo);
+            if (base16 && (d0 & 3) == 0 && d0 + kWalkChunkDw <= n_dw) {
+                // whole chunk in bounds and 16-byte aligned: all 16 loads in flight before the first LDS write
+                constexpr int kIt = kWalkChunkDw / (kWave * 4);
+                uint4 x[kIt];
+#pragma unroll
+                for (int it = 0; it < kIt; ++it) x[it] = *reinterpret_cast<const uint4*>(s32 + d0 + it * kWave * 4 + lane * 4);
+#pragma unroll
+                for (int it = 0; it < kIt; ++it) *reinterpret_cast<uint4*>(&s_chunk[it * kWave * 4 + lane * 4]) = x[it];
+            } else {
+                for (uint32_t i = lane * 4; i < (uint32_t)kWalkChunkDw; i += kWave * 4) {
+                    const uint64_t d = d0 + i;
+                    uint4 x;
+                    x.x = d < n_dw ? s32[d] : 0u; x.y = d + 1 < n_dw ? s32[d + 1] : 0u;
+                    x.z = d + 2 < n_dw ? s32[d + 2] : 0u; x.w = d + 3 < n_dw ? s32[d + 3] : 0u;
+                    *reinterpret_cast<uint4*>(&s_chunk[i]) = x;
+                }
+            }
+            // (no explicit wait: one wave, LDS operations execute in order; an s_waitcnt here would also wait for the
+            //  previous steps' width stores -- CDNA4 counts stores in vmcnt -- and serialise every step on HBM)
+        }
+        const uint32_t cb = b + lane;
+        const uint32_t cpos = pos + lane * stride;
+        const bool in_range = cb < g.n_blocks;
+        const bool readable = in_range && cpos < limit;
+        const uint32_t fbit = frame_sh + (readable ? cpos : pos);
+        const uint32_t li = (uint32_t)((int32_t)(fbit >> 5) - c_lo);
+        const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[li + 1], s_chunk[li], fbit & 31u);
+        const bool same = readable && (bits & 1u);                       // Terse.hpp:361
+        const uint64_t not_same = __ballot(!same);
+        const uint32_t first = not_same ? (uint32_t)__builtin_ctzll(not_same) : 64u;
+
+        if (lane < first) wf[cb] = (uint8_t)w_prev;
+        if (lane <= first && in_range && (cb & (kTileBlocks - 1)) == 0) tf[cb / kTileBlocks] = cpos;
+
+        if (first < 64u && b + first < g.n_blocks) {                     // explicit header at block b + first
+            uint32_t w = (bits >> 1) & 7u, hl = 4;                       // Terse.hpp:362 (every lane parses its own bits)
+            if (w == 7u) {
+                w += (bits >> 4) & 3u; hl = 6;                           // :365
+                if (w == 10u) { w += (bits >> 6) & 63u; hl = 12; }       // :368
+            }
+            const uint32_t e_w = (uint32_t)__builtin_amdgcn_readlane((int)w, first);
+            const uint32_t e_hl = (uint32_t)__builtin_amdgcn_readlane((int)hl, first);
+            const uint32_t e_ok = (uint32_t)__builtin_amdgcn_readlane((int)readable, first);
+            const uint32_t eb = b + first, epos = pos + first * stride;
+            if (!e_ok || e_w > max_w) { bad = true; break; }
+            const uint32_t nbv = eb + 1 == g.n_blocks ? nb_last : (uint32_t)kBlock;
+            if (lane == first) wf[cb] = (uint8_t)e_w;
+            pos = epos + e_hl + nbv * e_w;
+            w_prev = e_w;
+            b = eb + 1;
+            if (b == g.n_blocks) final_pos = pos;
+        } else {                                                         // every remaining candidate repeats w_prev
+            const uint32_t cnt = g.n_blocks - b < 64u ? g.n_blocks - b : 64u;
+            if (b + cnt == g.n_blocks) final_pos = pos + (cnt - 1) * stride + 1u + nb_last * w_prev;   // last block may be partial
+            pos += cnt * stride;
+            b += cnt;
+        }
+        if (pos > limit + 64u * 400u) { bad = true; break; }             // ran away (corrupt stream): stop before wrapping
+    }
+    const bool ok = !bad && final_pos <= limit && 1 + (uint64_t)final_pos / 8 == fe - fo;   // S_f (Terse.hpp:547)
+    if (!ok && lane == 0) atomicMax(&status[0], 5u);                     // TRPX_ERR_CORRUPT
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_unpack_tiles
+// ---------------------------------------------------------------------------------------------
+template <typename T> constexpr int unpack_sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
+template <typename T>
+constexpr int unpack_image_dwords() { return unpack_sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 12; }
+
+template <typename T> struct OutVec;
+template <> struct OutVec<uint8_t>  { typedef uint32_t type; };
+template <> struct OutVec<int8_t>   { typedef uint32_t type; };
+template <> struct OutVec<uint16_t> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct OutVec<int16_t>  { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct OutVec<uint32_t> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct OutVec<int32_t>  { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+
+// 12 decoded values (already sign/zero-extended to 32 bits) -> three vector stores of 4 values.
+template <typename T>
+__device__ __forceinline__ void store_block(T* __restrict__ dst, const uint32_t (&u)[kBlock]) {
+    using V = typename OutVec<T>::type;
+    constexpr int bits = PixelTraits<T>::bits;
+    V* q = reinterpret_cast<V*>(dst);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        union { V vec; uint32_t x[sizeof(V) / 4]; } o;
+        if constexpr (bits == 32) { o.x[0] = u[4 * i]; o.x[1] = u[4 * i + 1]; o.x[2] = u[4 * i + 2]; o.x[3] = u[4 * i + 3]; }
+        else if constexpr (bits == 16) {
+            o.x[0] = (u[4 * i] & 0xFFFFu) | (u[4 * i + 1] << 16);
+            o.x[1] = (u[4 * i + 2] & 0xFFFFu) | (u[4 * i + 3] << 16);
+        } else {
+            o.x[0] = (u[4 * i] & 0xFFu) | ((u[4 * i + 1] & 0xFFu) << 8) | ((u[4 * i + 2] & 0xFFu) << 16) | (u[4 * i + 3] << 24);
+        }
+        __builtin_nontemporal_store(o.vec, q + i);
+    }
+}
+
+// Extract the 12 W-bit fields that start at bit `q` of the LDS image; static shifts.
+template <typename T, int W>
+__device__ __forceinline__ void unpack_payload_w(const uint32_t* __restrict__ image, uint32_t q, uint32_t (&u)[kBlock]) {
+    constexpr int NBITS = kBlock * W;
+    constexpr int ND = (NBITS + 31) / 32;
+    const uint32_t d = q >> 5, s = q & 31u;
+    uint32_t raw[ND + 1];
+#pragma unroll
+    for (int j = 0; j <= ND; ++j) raw[j] = image[d + j];
+    uint32_t x[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) x[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], s);   // string aligned to bit 0
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k) {
+        const int bit = k * W;
+        uint32_t f = x[bit >> 5] >> (bit & 31);
+        if ((bit & 31) + W > 32) f |= x[(bit >> 5) + 1] << (32 - (bit & 31));
+        if (PixelTraits<T>::is_signed) u[k] = (uint32_t)((int32_t)(f << (32 - W)) >> (32 - W));   // sign-extend (:784-789)
+        else u[k] = W >= 32 ? f : f & ((1u << (W & 31)) - 1u);
+    }
+}
+
+template <typename T, int LO, int HI>
+struct UnpackDispatch {
+    static __device__ __forceinline__ void run(const uint32_t* image, uint32_t q, uint32_t w0, uint32_t (&u)[kBlock]) {
+        if constexpr (LO == HI) unpack_payload_w<T, LO>(image, q, u);
+        else {
+            constexpr int MID = (LO + HI) / 2;
+            if (w0 <= (uint32_t)MID) UnpackDispatch<T, LO, MID>::run(image, q, w0, u);
+            else UnpackDispatch<T, MID + 1, HI>::run(image, q, w0, u);
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                              const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                              uint32_t tiles_per_frame,
+                                                              const uint8_t* __restrict__ widths,
+                                                              const uint64_t* __restrict__ tile_off,
+                                                              T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+    constexpr int kSub = unpack_sub_tiles<T>();
+    constexpr int kImage = unpack_image_dwords<T>();
+    __shared__ uint32_t s_image[kImage];
+    __shared__ uint32_t s_wtot[kSub * 4];
+    if (status[0] != 0) return;                             // corrupt chain: produce nothing
+    const uint32_t tid = threadIdx.x;
+    const int lane = lane_id(), wave = wave_id();
+    const uint64_t tile = blockIdx.x;
+    const uint32_t frame = (uint32_t)(tile / tiles_per_frame);
+    const uint32_t t = (uint32_t)(tile % tiles_per_frame);
+    const uint32_t b0 = t * kSub * kThreads;
+    const uint8_t* __restrict__ wf = widths + (uint64_t)frame * g.n_blocks;
+
+    uint32_t w[kSub], hl[kSub], len[kSub], inc[kSub];
+    int nb[kSub];
+#pragma unroll
+    for (int r = 0; r < kSub; ++r) {
+        const uint32_t b = b0 + r * kThreads + tid;
+        nb[r] = 0; w[r] = 0; hl[r] = 0;
+        if (b < g.n_blocks) {
+            w[r] = wf[b];
+            const uint32_t w_prev = b ? wf[b - 1] : 0u;     // significant_bits = 0 at frame start (Terse.hpp:359)
+            const uint64_t first = (uint64_t)b * kBlock;
+            nb[r] = first + kBlock <= g.n_values ? kBlock : (int)(g.n_values - first);
+            hl[r] = header_len(w[r], w_prev);
+        }
+        len[r] = nb[r] ? hl[r] + (uint32_t)nb[r] * w[r] : 0u;
+        inc[r] = wave_inclusive_scan(len[r]);
+        if (lane == 63) s_wtot[r * 4 + wave] = inc[r];
+    }
+    __syncthreads();
+    // every wave: exclusive scan of the 16 (round, wave) piece sizes
+    uint32_t off[kSub];
+    uint32_t tile_bits;
+    {
+        const uint32_t tot = lane < kSub * 4 ? s_wtot[lane] : 0u;
+        const uint32_t incl = wave_inclusive_scan(tot);
+        const uint32_t excl = incl - tot;
+#pragma unroll
+        for (int r = 0; r < kSub; ++r)
+            off[r] = (uint32_t)__shfl((int)excl, r * 4 + wave, 64) + inc[r] - len[r];   // tile-relative bit of my block
+        tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, kSub * 4 - 1);
+    }
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    const uint64_t t_off = tile_off[(uint64_t)frame * g.n_tiles + (uint64_t)t * kSub];   // walk records every 256 blocks
+    if (t_off + tile_bits > 8 * (fe - fo) || fe > terse_bytes) {      // chain / index inconsistent with the frame
+        if (tid == 0) atomicMax(&status[0], 5u);
+        return;
+    }
+    // ---- stage the tile's stream bits [a0, a0 + tile_bits) in LDS, 16 bytes per lane, coalesced ----------
+    const uint64_t a0 = 8 * fo + t_off;
+    const uint64_t d_lo = (a0 >> 5) & ~3ull;                 // 16-byte aligned start (terse is 4-byte aligned: use dwords)
+    const uint32_t n_dw = (uint32_t)(((a0 + tile_bits + 31) >> 5) - d_lo) + 1;   // + 1: alignbit peeks one dword further
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(terse);
+    const uint64_t total_dw = (terse_bytes + 3) / 4;
+    const bool base16 = ((uintptr_t)terse & 15) == 0;
+    for (uint32_t i = tid * 4; i < n_dw; i += kThreads * 4) {
+        const uint64_t d = d_lo + i;
+        uint4 x;
+        if (base16 && d + 4 <= total_dw) x = *reinterpret_cast<const uint4*>(s32 + d);
+        else {
+            x.x = d < total_dw ? s32[d] : 0u; x.y = d + 1 < total_dw ? s32[d + 1] : 0u;
+            x.z = d + 2 < total_dw ? s32[d + 2] : 0u; x.w = d + 3 < total_dw ? s32[d + 3] : 0u;
+        }
+        *reinterpret_cast<uint4*>(&s_image[i]) = x;
+    }
+    __syncthreads();
+    const uint32_t img_bit0 = (uint32_t)(a0 - 32 * d_lo);   // image bit of the tile's first bit (< 128)
+
+    // ---- extract + store ----------------------------------------------------------------------------------
+    T* __restrict__ fout = pixels_out + (uint64_t)frame * g.n_values;
+#pragma unroll
+    for (int r = 0; r < kSub; ++r) {
+        const uint32_t b = b0 + r * kThreads + tid;
+        const uint32_t q = img_bit0 + off[r] + hl[r];       // first payload bit in the image
+        uint32_t u[kBlock];
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) u[k] = 0u;         // w == 0 -> zeros (Terse.hpp:373-374)
+        uint64_t todo = __ballot(nb[r] == kBlock && w[r] != 0u);
+        while (todo) {
+            const int l0 = __builtin_ctzll(todo);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w[r], l0);
+            const bool mine = nb[r] == kBlock && w[r] == w0;
+            uint32_t qq = q;
+            asm volatile("" : "+v"(qq));                    // keep the specialised bodies out of LICM's reach
+            if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(s_image, qq, w0 > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w0, u);
+            todo &= ~__ballot(mine);
+        }
+        if (nb[r] == kBlock) {
+            if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
+            store_block<T>(fout + (uint64_t)b * kBlock, u);
+        } else if (nb[r]) {                                 // the frame's last, partial block: generic
+            const uint32_t ww = w[r] > (uint32_t)PixelTraits<T>::bits ? 0u : w[r];
+            const uint32_t mask = ww >= 32u ? 0xFFFFFFFFu : ((1u << ww) - 1u);
+            uint32_t p = q;
+            for (int k = 0; k < nb[r]; ++k) {
+                uint32_t f = 0;
+                if (ww) {
+                    const uint64_t two = (uint64_t)s_image[p >> 5] | ((uint64_t)s_image[(p >> 5) + 1] << 32);
+                    f = (uint32_t)(two >> (p & 31u)) & mask;
+                    if (PixelTraits<T>::is_signed) f = (uint32_t)((int32_t)(f << (32u - ww)) >> (32u - ww));
+                }
+                fout[(uint64_t)b * kBlock + k] = (T)f;
+                p += ww;
+            }
+        }
+    }
+}
+
+template <typename T>
+static hipError_t launch_decode_fast_t(const DecodeArgs& a, hipStream_t st) {
+    const FrameGeom g = a.geom;
+    constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
+    const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
+    const uint32_t max_w = PixelTraits<T>::bits;
+    hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
+    if (e != hipSuccess) return e;
+    Profiler& prof = profiler();
+    prof.begin();
+    prof.mark(st);
+    hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, g, max_w, a.widths, a.tile_off, a.status);
+    prof.mark(st);
+    hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
+                       (uint64_t)a.terse_bytes, a.frame_offsets, g, tpf, a.widths, a.tile_off,
+                       static_cast<T*>(a.pixels_out), a.status);
+    prof.mark(st);
+    return hipGetLastError();
+}
+
+// Fast path preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned.
+hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_decode_fast_t<uint8_t>(a, st);
+    case 1: return launch_decode_fast_t<int8_t>(a, st);
+    case 2: return launch_decode_fast_t<uint16_t>(a, st);
+    case 3: return launch_decode_fast_t<int16_t>(a, st);
+    case 4: return launch_decode_fast_t<uint32_t>(a, st);
+    case 5: return launch_decode_fast_t<int32_t>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace trpx

@@ -40,6 +40,8 @@ hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStream_t st);
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
+// tuned decode (decode_fast.hip): needs frame offsets, n_values % 4 == 0 and 16-byte aligned pixels_out
+hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 hipError_t launch_synth(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
                         void* out, hipStream_t st);
