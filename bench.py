@@ -125,7 +125,7 @@ def main():
     def step():
         enc = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
         if world > 1:   # per-frame size gather over xGMI -> global byte offsets of every frame
-            sharded.gather_global_offsets(offs, st_e[1:2])
+            sharded.gather_global_offsets(offs, st_e[1:2], counts=[frames] * world)
         # decode straight from the device-resident stack (bounded by its worst-case capacity; the
         # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
         codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)

@@ -32,6 +32,9 @@ def _worker(rank, world, port, total_frames, q):
     local_offsets = torch.zeros(hi - lo + 1, dtype=torch.int64)
     local_offsets[1:] = torch.cumsum(torch.from_numpy(sizes.astype(np.int64)), 0)
     goffs, base, gpb = sharded.gather_global_offsets(local_offsets, torch.tensor([pb]))
+    counts = [sharded.frame_range(total_frames, r, world)[1] - sharded.frame_range(total_frames, r, world)[0] for r in range(world)]
+    goffs2, base2, gpb2 = sharded.gather_global_offsets(local_offsets, torch.tensor([pb]), counts=counts)
+    assert torch.equal(goffs, goffs2) and int(base) == int(base2) and int(gpb) == int(gpb2)
     q.put((rank, goffs.numpy().copy(), int(base), int(gpb), data.tobytes()))
     dist.barrier()
     dist.destroy_process_group()

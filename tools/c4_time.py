@@ -1,0 +1,25 @@
+"""configs[3]: 4096x4096 int32 synth-v1 frames with sparse peaks -- encode / decode timing + parity anchors."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from trpx_amd import codec, _lib
+L = _lib.lib()
+frames, n = 8, 4096 * 4096
+px = codec.synth(np.int32, 0, frames, n)
+ws = codec.Workspace("cuda")
+enc = codec.encode(px, workspace=ws); torch.cuda.synchronize(); enc.check()
+total = enc.total_bytes()
+back, st = codec.decode(enc.data, enc.frame_offsets, n, frames, np.int32, workspace=ws); torch.cuda.synchronize()
+assert int(st[0].item()) == 0 and torch.equal(back, px)
+L.trpx_profile_enable(1)
+buf = (C.c_float * 8)(); e, d = [], []
+for _ in range(5):
+    codec.encode(px, out=enc.data, workspace=ws, frame_offsets=enc.frame_offsets, status=enc.status)
+    k = L.trpx_profile_read(buf, 8); e.append([buf[i] for i in range(k)])
+    codec.decode(enc.data, enc.frame_offsets, n, frames, np.int32, out=back, workspace=ws, status=st)
+    k = L.trpx_profile_read(buf, 8); d.append([buf[i] for i in range(k)])
+e, d = np.median(np.array(e), 0), np.median(np.array(d), 0)
+pix = frames * n * 4
+print("size frame0", int(enc.frame_offsets[1]), "total", total, "prolix_bits", enc.prolix_bits())
+print("encode stages ms", e, "-> fps", frames / e.sum() * 1e3, "pixel GB/s", pix / e.sum() / 1e6, "algorithmic GB/s", (pix + total) / e.sum() / 1e6)
+print("decode stages ms", d, "-> fps", frames / d.sum() * 1e3, "pixel GB/s", pix / d.sum() / 1e6)

@@ -6,13 +6,14 @@ import numpy as np, torch
 from trpx_amd import codec, _lib
 L = _lib.lib()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+TB = int(os.environ.get("TRPX_TILE_BLOCKS", "1024"))
 n = 512 * 512
 px = codec.synth(np.uint16, 0, frames, n)
 ws = codec.Workspace("cuda")
 for _ in range(3):
     enc = codec.encode(px, workspace=ws)
 torch.cuda.synchronize()
-tpf = (21846 + 1023) // 1024
+tpf = (21846 + TB - 1) // TB
 tiles = frames * tpf
 # workspace layout (api.hip enc_ws): [two-pass arrays][fused descriptors][stamps]
 t256 = frames * ((21846 + 255) // 256)

@@ -46,20 +46,31 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
     const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);
 
     // All positions are frame-relative bit offsets in 32 bits (the launcher routes frames of >= 2^32 bits
-    // to the basic path); everything that steers the loop is wave-uniform and lives in SGPRs.
+    // to the basic path); everything that steers the loop is wave-uniform and lives in SGPRs: the serial
+    // chain per step is one LDS read, one ballot and a few scalar instructions.
     const uint32_t limit = (uint32_t)limit_bits;
     const uint64_t frame_dw = frame_abit >> 5;        // absolute dword of the frame's first bit
     const uint32_t frame_sh = (uint32_t)(frame_abit & 31);
+    const uint32_t n_blocks = g.n_blocks;
     int32_t c_lo = 0, c_hi = 0;                       // frame-relative dword range [c_lo, c_hi) held in s_chunk
                                                       // (c_lo may be -1..-3: chunks start on absolute 16-byte boundaries)
     uint32_t b = 0, w_prev = 0, pos = 0, final_pos = 0;
     bool bad = false;
-    while (b < g.n_blocks) {
+#ifdef TRPX_WALK_STATS
+    uint64_t st_t0 = __builtin_amdgcn_s_memtime(), st_refill = 0; uint32_t st_steps = 0, st_refills = 0;
+#endif
+    while (b < n_blocks) {
+#ifdef TRPX_WALK_STATS
+        ++st_steps;
+#endif
         const uint32_t stride = 1u + kBlock * w_prev;
-        // dwords needed this step: candidates pos .. pos + 63*stride, each peeking 2 dwords
+        // dwords needed this step: candidates pos .. pos + 63*stride, each peeking 12 bits (2 dwords)
         const uint32_t need_lo = (frame_sh + pos) >> 5;
         const uint32_t need_hi = ((frame_sh + pos + 63u * stride) >> 5) + 2;
         if ((int32_t)need_lo < c_lo || (int32_t)need_hi > c_hi) {   // refill (wave-uniform), 16-byte coalesced
+#ifdef TRPX_WALK_STATS
+            const uint64_t rt0 = __builtin_amdgcn_s_memtime(); ++st_refills;
+#endif
             c_lo = (int32_t)(((frame_dw + need_lo) & ~3ull) - frame_dw);
             c_hi = c_lo + kWalkChunkDw;
             const uint64_t d0 = (uint64_t)((int64_t)frame_dw + c_lo);
@@ -80,50 +91,62 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
                     *reinterpret_cast<uint4*>(&s_chunk[i]) = x;
                 }
             }
+#ifdef TRPX_WALK_STATS
+            __builtin_amdgcn_s_waitcnt(0); st_refill += __builtin_amdgcn_s_memtime() - rt0;
+#endif
             // (no explicit wait: one wave, LDS operations execute in order; an s_waitcnt here would also wait for the
             //  previous steps' width stores -- CDNA4 counts stores in vmcnt -- and serialise every step on HBM)
         }
-        const uint32_t cb = b + lane;
-        const uint32_t cpos = pos + lane * stride;
-        const bool in_range = cb < g.n_blocks;
-        const bool readable = in_range && cpos < limit;
-        const uint32_t fbit = frame_sh + (readable ? cpos : pos);
-        const uint32_t li = (uint32_t)((int32_t)(fbit >> 5) - c_lo);
-        const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[li + 1], s_chunk[li], fbit & 31u);
-        const bool same = readable && (bits & 1u);                       // Terse.hpp:361
-        const uint64_t not_same = __ballot(!same);
-        const uint32_t first = not_same ? (uint32_t)__builtin_ctzll(not_same) : 64u;
+        // every lane peeks at its candidate (bits past the frame's end read as whatever follows: harmless, the
+        // chain is validated against S_f at the end and b never passes n_blocks)
+        const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;   // bit index inside s_chunk
+        const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
+        const uint32_t left = n_blocks - b;                                // candidates that are real blocks
+        const uint64_t valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+        const uint64_t same = __ballot((bits & 1u) != 0u) & valid;         // Terse.hpp:361
+        const uint64_t stop = ~same;                                       // first explicit header or end of frame
+        const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
 
-        if (lane < first) wf[cb] = (uint8_t)w_prev;
-        if (lane <= first && in_range && (cb & (kTileBlocks - 1)) == 0) tf[cb / kTileBlocks] = cpos;
-
-        if (first < 64u && b + first < g.n_blocks) {                     // explicit header at block b + first
-            uint32_t w = (bits >> 1) & 7u, hl = 4;                       // Terse.hpp:362 (every lane parses its own bits)
+        uint32_t e_w = w_prev;
+        const bool explicit_hdr = first < left && first < 64u;             // block b + first has an explicit header
+        uint32_t new_pos, new_b;
+        if (explicit_hdr) {
+            const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, first);   // scalar parse (Terse.hpp:362-370)
+            uint32_t w = (eb >> 1) & 7u, hl = 4;
             if (w == 7u) {
-                w += (bits >> 4) & 3u; hl = 6;                           // :365
-                if (w == 10u) { w += (bits >> 6) & 63u; hl = 12; }       // :368
+                w += (eb >> 4) & 3u; hl = 6;
+                if (w == 10u) { w += (eb >> 6) & 63u; hl = 12; }
             }
-            const uint32_t e_w = (uint32_t)__builtin_amdgcn_readlane((int)w, first);
-            const uint32_t e_hl = (uint32_t)__builtin_amdgcn_readlane((int)hl, first);
-            const uint32_t e_ok = (uint32_t)__builtin_amdgcn_readlane((int)readable, first);
-            const uint32_t eb = b + first, epos = pos + first * stride;
-            if (!e_ok || e_w > max_w) { bad = true; break; }
-            const uint32_t nbv = eb + 1 == g.n_blocks ? nb_last : (uint32_t)kBlock;
-            if (lane == first) wf[cb] = (uint8_t)e_w;
-            pos = epos + e_hl + nbv * e_w;
-            w_prev = e_w;
-            b = eb + 1;
-            if (b == g.n_blocks) final_pos = pos;
-        } else {                                                         // every remaining candidate repeats w_prev
-            const uint32_t cnt = g.n_blocks - b < 64u ? g.n_blocks - b : 64u;
-            if (b + cnt == g.n_blocks) final_pos = pos + (cnt - 1) * stride + 1u + nb_last * w_prev;   // last block may be partial
-            pos += cnt * stride;
-            b += cnt;
+            if (w > max_w) { bad = true; break; }
+            e_w = w;
+            const uint32_t nbv = b + first + 1 == n_blocks ? nb_last : (uint32_t)kBlock;
+            new_pos = pos + first * stride + hl + nbv * w;
+            new_b = b + first + 1;
+            if (new_b == n_blocks) final_pos = new_pos;
+        } else {                                                           // every remaining candidate repeats w_prev
+            const uint32_t cnt = left < 64u ? left : 64u;
+            if (cnt == left) final_pos = pos + (cnt - 1) * stride + 1u + nb_last * w_prev;   // last block may be partial
+            new_pos = pos + cnt * stride;
+            new_b = b + cnt;
         }
-        if (pos > limit + 64u * 400u) { bad = true; break; }             // ran away (corrupt stream): stop before wrapping
+        // widths of the blocks consumed by this step: w_prev for the run, e_w for the explicit block
+        const uint32_t n_done = new_b - b;
+        if (lane < n_done) wf[b + lane] = (uint8_t)(lane < first ? w_prev : e_w);
+        // bit offset of every 256-block group that starts inside this step
+        if (((b + n_done - 1) ^ (b - 1)) >= (uint32_t)kTileBlocks || b == 0) {
+            const uint32_t cb = b + lane;
+            if (lane < n_done && (cb & (kTileBlocks - 1)) == 0) tf[cb / kTileBlocks] = pos + lane * stride;
+        }
+        pos = new_pos;
+        w_prev = e_w;
+        b = new_b;
+        if (pos > limit + 64u * 400u) { bad = true; break; }               // ran away (corrupt stream): stop before wrapping
     }
     const bool ok = !bad && final_pos <= limit && 1 + (uint64_t)final_pos / 8 == fe - fo;   // S_f (Terse.hpp:547)
     if (!ok && lane == 0) atomicMax(&status[0], 5u);                     // TRPX_ERR_CORRUPT
+#ifdef TRPX_WALK_STATS
+    if (lane == 0) { atomicAdd(&status[2], st_steps); atomicAdd(&status[3], st_refills); atomicAdd(&status[4], (uint32_t)(st_refill >> 4)); atomicAdd(&status[5], (uint32_t)((__builtin_amdgcn_s_memtime() - st_t0) >> 4)); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -157,7 +180,7 @@ __device__ __forceinline__ void store_block(T* __restrict__ dst, const uint32_t 
         } else {
             o.x[0] = (u[4 * i] & 0xFFu) | ((u[4 * i + 1] & 0xFFu) << 8) | ((u[4 * i + 2] & 0xFFu) << 16) | (u[4 * i + 3] << 24);
         }
-        __builtin_nontemporal_store(o.vec, q + i);
+        __builtin_nontemporal_store(o.vec, q + i);   // (plain stores remove the 1.23x partial-write traffic but run 17 % slower)
     }
 }
 

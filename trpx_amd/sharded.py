@@ -18,7 +18,7 @@ def frame_range(n_frames_total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.Tensor | None = None,
-                          group=None):
+                          group=None, counts: list[int] | None = None):
     """All-gather the per-frame sizes of every rank and prefix-sum them.
 
     local_offsets: int64 [f_local + 1] (byte offsets of the local stack, as trpx_encode writes them).
@@ -31,10 +31,13 @@ def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.
     if world == 1:
         pb = local_prolix_bits.max() if local_prolix_bits is not None else None
         return local_offsets.clone(), torch.zeros((), dtype=torch.int64, device=local_offsets.device), pb
-    counts = torch.tensor([sizes.numel()], dtype=torch.int64, device=sizes.device)
-    all_counts = torch.empty(world, dtype=torch.int64, device=sizes.device)
-    dist.all_gather_into_tensor(all_counts, counts, group=group)
-    counts_host = [int(c) for c in all_counts.tolist()]
+    if counts is not None:                                  # shard sizes known up front: no host round trip
+        counts_host = [int(c) for c in counts]
+    else:
+        my_count = torch.tensor([sizes.numel()], dtype=torch.int64, device=sizes.device)
+        all_counts = torch.empty(world, dtype=torch.int64, device=sizes.device)
+        dist.all_gather_into_tensor(all_counts, my_count, group=group)
+        counts_host = [int(c) for c in all_counts.tolist()]
     fmax = max(counts_host)
     padded = torch.zeros(fmax + 1, dtype=torch.int64, device=sizes.device)
     padded[: sizes.numel()] = sizes
