@@ -172,6 +172,17 @@ def main():
         torch.cuda.synchronize()
         enc_ms = ev[0].elapsed_time(ev[1]) / reps
         dec_ms = ev[1].elapsed_time(ev[2]) / reps
+        # walk-free decode with the encoder's optional decode index (not part of `value`)
+        enc_i = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e, index=True)
+        torch.cuda.synchronize()
+        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev2[0].record()
+        for _ in range(reps):
+            codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, status=st_d, index=enc_i.index)
+        ev2[1].record()
+        torch.cuda.synchronize()
+        dec_idx_ms = ev2[0].elapsed_time(ev2[1]) / reps
+        assert int(st_d[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
         # per-kernel durations: HIP events recorded by the library on the launch stream
         L.trpx_profile_enable(1)
         stage = {n: [] for n in ENC_STAGES_TWOPASS + ENC_STAGES_FUSED + DEC_STAGES}
@@ -197,6 +208,7 @@ def main():
             "decode_algorithmic_GBps": (pix_bytes + total_bytes) / dec_ms / 1e6,
             "encode_pixel_frac_of_hbm_peak": pix_bytes / enc_ms / 1e6 / HBM_PEAK_GBPS,
             "decode_pixel_frac_of_hbm_peak": pix_bytes / dec_ms / 1e6 / HBM_PEAK_GBPS,
+            "decode_with_index_ms": dec_idx_ms, "decode_with_index_fps": frames / dec_idx_ms * 1e3,
             "kernel_ms": stage_ms, "compressed_bytes_per_gpu": total_bytes,
             "compression_ratio": total_bytes / pix_bytes,
         }

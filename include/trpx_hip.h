@@ -110,6 +110,28 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
                 void* stream);
 
 /*
+ * Decode index.  The .trpx stream stores no index, so a plain trpx_decode first walks
+ * every frame's header chain (serial per frame, Terse.hpp:360-372).  An encoder that is about to decode its
+ * own stack again -- or a reader that decodes a stack more than once -- can keep what that walk produces:
+ * width[b] (1 byte per block) and the bit offset of every 256-block group.  The index is an opaque DEVICE
+ * buffer of trpx_index_bytes(); it is NOT part of the bitstream (files stay byte-identical).
+ *   trpx_encode_indexed   = trpx_encode that also fills `index` (index == NULL: plain trpx_encode)
+ *   trpx_build_index      fills `index` from an existing stack (the walk alone)
+ *   trpx_decode_indexed   = trpx_decode without the walk; the index is validated against the frame sizes
+ *                           (inconsistent -> status[0] = TRPX_ERR_CORRUPT), frame_offsets is mandatory
+ */
+size_t trpx_index_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
+int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block,
+                        uint8_t* out, size_t out_capacity, uint64_t* frame_offsets, uint32_t* status,
+                        void* index, void* workspace, size_t workspace_bytes, void* stream);
+int trpx_build_index(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                     size_t n_values, size_t n_frames, unsigned block, void* index, uint32_t* status,
+                     void* stream);
+int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                        const uint64_t* frame_offsets, const void* index, size_t n_values, size_t n_frames,
+                        unsigned block, void* pixels_out, uint32_t* status, void* stream);
+
+/*
  * Host-pointer convenience wrappers (what the C++ trpx::Terse class calls): allocate device
  * staging, copy in, run the device entry point, copy out, synchronise.  `out` must hold
  * n_frames * trpx_worst_case_bytes(); *total_bytes receives sum(S_f); frame_offsets (host,

@@ -300,3 +300,42 @@ def test_cpp_drop_in_example(gpu, tmp_path):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
     r = subprocess.run([exe, str(tmp_path / "junk.terse")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_decode_index_side_channel(gpu, oracle):
+    """the encoder's decode index == the index the header walk builds from the stream, and
+    walk-free decode with it is pixel-identical (u16 1024-block tiles, int32 512-block tiles, ragged frame end,
+    both encoder paths)."""
+    import torch
+    from trpx_amd import codec, _lib
+    for dt, n, frames in ((np.uint16, 512 * 512, 9), (np.int32, 700 * 700, 3), (np.uint16, 12 * 1024 * 3 + 16, 5)):
+        px = codec.synth(dt, 11, frames, n, device=gpu)
+        for path in (0, 1):
+            _lib.lib().trpx_set_encode_path(path)
+            try:
+                enc = codec.encode(px, index=True)
+            finally:
+                _lib.lib().trpx_set_encode_path(0)
+            torch.cuda.synchronize()
+            enc.check()
+            walked = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, dt)
+            torch.cuda.synchronize()
+            # the index buffers are only defined where a block / group exists: compare through a decode and bytewise
+            nb = (n + 11) // 12
+            ng = (nb + 255) // 256
+            w_off = (8 * frames * ng + 15) // 16 * 16
+            assert torch.equal(enc.index[: 8 * frames * ng], walked[: 8 * frames * ng]), (dt, n, path)
+            assert torch.equal(enc.index[w_off: w_off + frames * nb], walked[w_off: w_off + frames * nb]), (dt, n, path)
+            back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt, index=enc.index)
+            torch.cuda.synchronize()
+            assert int(st[0].item()) == 0
+            assert torch.equal(back.view(torch.int32 if dt == np.int32 else torch.int16),
+                               px.view(torch.int32 if dt == np.int32 else torch.int16))
+    # a wrong index is rejected, not decoded into garbage silently
+    px = codec.synth(np.uint16, 0, 2, 512 * 512, device=gpu)
+    enc = codec.encode(px, index=True)
+    bad = enc.index.clone()
+    bad[0:8] = 255                                         # first group offset far beyond the frame
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, 512 * 512, 2, np.uint16, index=bad)
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == _lib.ERR_CORRUPT

@@ -42,6 +42,10 @@ SYMBOLS = {
     "trpx_decode_workspace_bytes": (_SZ, [_I, _SZ, _SZ, _U]),
     "trpx_encode": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "trpx_decode": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P, _SZ, _P]),
+    "trpx_index_bytes": (_SZ, [_I, _SZ, _SZ, _U]),
+    "trpx_encode_indexed": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
+    "trpx_build_index": (_I, [_I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P]),
+    "trpx_decode_indexed": (_I, [_I, _I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _P, _P, _P]),
     "trpx_encode_host": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, C.POINTER(_SZ), _P, C.POINTER(_U), _I]),
     "trpx_decode_host": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _I]),
     "trpx_frame_offsets_host": (_I, [_P, _SZ, _SZ, _SZ, _U, _U, _P, _I]),

@@ -46,6 +46,7 @@ class Encoded:
     n_values: int
     n_frames: int
     dtype: torch.dtype
+    index: torch.Tensor | None = None   # optional decode index (trpx_encode_indexed)
 
     def total_bytes(self) -> int:
         return int(self.frame_offsets[-1].item())
@@ -75,9 +76,13 @@ class Workspace:
         return self.buf
 
 
+def index_bytes(dtype, n_values: int, n_frames: int, block: int = BLOCK) -> int:
+    return lib().trpx_index_bytes(dtype_code(dtype), n_values, n_frames, block)
+
+
 def encode(pixels: torch.Tensor, out: torch.Tensor | None = None, workspace: Workspace | None = None,
            frame_offsets: torch.Tensor | None = None, status: torch.Tensor | None = None,
-           block: int = BLOCK) -> Encoded:
+           block: int = BLOCK, index: torch.Tensor | bool | None = None) -> Encoded:
     """Encode a [n_frames, n_values] (or [n_frames, H, W]) stack resident on the GPU.
 
     Asynchronous on the current stream; call ``Encoded.check()`` (synchronises) to test status."""
@@ -97,17 +102,20 @@ def encode(pixels: torch.Tensor, out: torch.Tensor | None = None, workspace: Wor
         status = torch.empty(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
     ws_bytes = lib().trpx_encode_workspace_bytes(code, n_values, n_frames, block)
     ws = (workspace or Workspace(dev)).get(ws_bytes)
+    if index is True:     # also keep the decode index (not part of the bitstream)
+        index = torch.empty(index_bytes(px.dtype, n_values, n_frames, block), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib().trpx_encode(code, px.data_ptr(), n_values, n_frames, block, out.data_ptr(), out.numel(),
-                                frame_offsets.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
-                                _stream_ptr(px)))
-    return Encoded(out, frame_offsets, status, n_values, n_frames, px.dtype)
+        check(lib().trpx_encode_indexed(code, px.data_ptr(), n_values, n_frames, block, out.data_ptr(), out.numel(),
+                                        frame_offsets.data_ptr(), status.data_ptr(),
+                                        index.data_ptr() if index is not None else None, ws.data_ptr(), ws.numel(),
+                                        _stream_ptr(px)))
+    return Encoded(out, frame_offsets, status, n_values, n_frames, px.dtype, index if index is not None else None)
 
 
 def decode(terse: torch.Tensor, frame_offsets: torch.Tensor | None, n_values: int, n_frames: int, dtype,
            out: torch.Tensor | None = None, workspace: Workspace | None = None,
            status: torch.Tensor | None = None, stream_signed: bool | None = None,
-           block: int = BLOCK):
+           block: int = BLOCK, index: torch.Tensor | None = None):
     """Decode a stack resident on the GPU. Returns (pixels [n_frames, n_values], status)."""
     tdt = torch_dtype(dtype)
     code = dtype_code(tdt)
@@ -118,6 +126,12 @@ def decode(terse: torch.Tensor, frame_offsets: torch.Tensor | None, n_values: in
         out = torch.empty((n_frames, n_values), dtype=tdt, device=dev)
     if status is None:
         status = torch.empty(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+    if index is not None:   # walk-free decode with a previously kept index
+        with torch.cuda.device(dev):
+            check(lib().trpx_decode_indexed(int(stream_signed), code, terse.data_ptr(), terse.numel(),
+                                            frame_offsets.data_ptr(), index.data_ptr(), n_values, n_frames, block,
+                                            out.data_ptr(), status.data_ptr(), _stream_ptr(terse)))
+        return out, status
     ws_bytes = lib().trpx_decode_workspace_bytes(code, n_values, n_frames, block)
     ws = (workspace or Workspace(dev)).get(ws_bytes)
     with torch.cuda.device(dev):
@@ -126,6 +140,19 @@ def decode(terse: torch.Tensor, frame_offsets: torch.Tensor | None, n_values: in
                                 n_values, n_frames, block, out.data_ptr(), status.data_ptr(), ws.data_ptr(),
                                 ws.numel(), _stream_ptr(terse)))
     return out, status
+
+
+def build_index(terse: torch.Tensor, frame_offsets: torch.Tensor, n_values: int, n_frames: int, dtype,
+                block: int = BLOCK) -> torch.Tensor:
+    """Walk an existing stack once and keep the decode index (trpx_build_index)."""
+    code = dtype_code(torch_dtype(dtype))
+    dev = terse.device
+    index = torch.empty(index_bytes(dtype, n_values, n_frames, block), dtype=torch.uint8, device=dev)
+    status = torch.empty(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().trpx_build_index(code, terse.data_ptr(), terse.numel(), frame_offsets.data_ptr(), n_values,
+                                     n_frames, block, index.data_ptr(), status.data_ptr(), _stream_ptr(terse)))
+    return index
 
 
 def synth(dtype, frame0: int, n_frames: int, n_values: int, device="cuda", seed: int = 20240807) -> torch.Tensor:

@@ -65,6 +65,14 @@ int g_encode_path = [] {
     const char* e = getenv("TRPX_ENCODE_PATH");
     return e && strcmp(e, "twopass") == 0 ? 1 : 0;
 }();
+struct IdxLayout { size_t group_off, widths, total; };
+IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
+    IdxLayout l;
+    l.group_off = 0;
+    l.widths = trpx::align_up(8 * n_frames * (size_t)g.n_tiles, 16);
+    l.total = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);
+    return l;
+}
 struct DecWs { size_t walk_offsets, tile_off, widths, total; };
 DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     DecWs w;
@@ -117,9 +125,26 @@ size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, 
     return dec_ws(g, n_frames).total;
 }
 
+static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                            size_t n_values, size_t n_frames, unsigned block, void* index, uint32_t* status,
+                            bool clear_status, void* stream);
+
+size_t trpx_index_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g)) return 0;
+    return idx_layout(g, n_frames).total;
+}
+
 int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
                 size_t out_capacity, uint64_t* frame_offsets, uint32_t* status, void* workspace,
                 size_t workspace_bytes, void* stream) {
+    return trpx_encode_indexed(dtype, pixels, n_values, n_frames, block, out, out_capacity, frame_offsets, status,
+                               nullptr, workspace, workspace_bytes, stream);
+}
+
+int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
+                        size_t out_capacity, uint64_t* frame_offsets, uint32_t* status, void* index,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: unknown dtype %d", dtype);
     if (block != (unsigned)trpx::kBlock)
@@ -147,11 +172,18 @@ int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames,
     a.frame_size = reinterpret_cast<uint64_t*>(ws + w.frame_size);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.tile_bits = reinterpret_cast<uint32_t*>(ws + w.tile_bits);
+    if ((uintptr_t)index % 16) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode_indexed: index must be 16-byte aligned");
+    const IdxLayout il = idx_layout(g, n_frames);
+    a.idx_group_off = index ? reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off) : nullptr;
+    a.idx_widths = index ? reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths) : nullptr;
     const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0;
     if (g_encode_path == 0 && vec_ok)
         HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
-    else
+    else {
         HIP_TRY(trpx::launch_encode(dtype, a, static_cast<hipStream_t>(stream)));
+        if (index && out)   // the two-pass pipeline does not emit the index: build it from the stream it just wrote
+            return build_index_impl(dtype, out, out_capacity, frame_offsets, n_values, n_frames, block, index, status, false, stream);
+    }
     return TRPX_OK;
 }
 
@@ -190,9 +222,69 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     static const bool basic = getenv("TRPX_DECODE_PATH") && strcmp(getenv("TRPX_DECODE_PATH"), "basic") == 0;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
     if (frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0)
-        HIP_TRY(trpx::launch_decode_fast(out_dtype, a, static_cast<hipStream_t>(stream)));
+        HIP_TRY(trpx::launch_decode_fast(out_dtype, a, false, static_cast<hipStream_t>(stream)));
     else
         HIP_TRY(trpx::launch_decode(out_dtype, a, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                            size_t n_values, size_t n_frames, unsigned block, void* index, uint32_t* status,
+                            bool clear_status, void* stream) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !n_frames || !terse_bytes)
+        return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG, "trpx_build_index: bad dtype/sizes/block");
+    if (!terse || !frame_offsets || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: null pointer");
+    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: misaligned pointer");
+    if (8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) >= 0xF0000000ull)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: frames of >= 2^32 bits");
+    const IdxLayout il = idx_layout(g, n_frames);
+    trpx::DecodeArgs a{};
+    a.terse = terse;
+    a.terse_bytes = terse_bytes;
+    a.frame_offsets = frame_offsets;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.status = status;
+    a.tile_off = reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off);
+    a.widths = reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths);
+    HIP_TRY(trpx::launch_walk_only(a, (uint32_t)(8 * trpx_dtype_size(dtype)), clear_status, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+int trpx_build_index(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                     size_t n_values, size_t n_frames, unsigned block, void* index, uint32_t* status, void* stream) {
+    return build_index_impl(dtype, terse, terse_bytes, frame_offsets, n_values, n_frames, block, index, status, true, stream);
+}
+
+int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                        const uint64_t* frame_offsets, const void* index, size_t n_values, size_t n_frames,
+                        unsigned block, void* pixels_out, uint32_t* status, void* stream) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(out_dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: unknown dtype %d", out_dtype);
+    if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: block=%u", block);
+    if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: only same-signedness decode (Terse.hpp:356-357)");
+    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: bad sizes");
+    if (!terse || !pixels_out || !status || !index || !frame_offsets)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: null pointer");
+    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 || (uintptr_t)pixels_out % 16 ||
+        n_values % 4)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: needs n_values %% 4 == 0, 16-byte aligned pixels_out/index");
+    const IdxLayout il = idx_layout(g, n_frames);
+    trpx::DecodeArgs a{};
+    a.terse = terse;
+    a.terse_bytes = terse_bytes;
+    a.frame_offsets = frame_offsets;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.pixels_out = pixels_out;
+    a.status = status;
+    a.tile_off = reinterpret_cast<uint64_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.group_off);
+    a.widths = reinterpret_cast<uint8_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.widths);
+    HIP_TRY(trpx::launch_decode_fast(out_dtype, a, true, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }
 

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __r
     }
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     const uint64_t t_off = tile_off[(uint64_t)frame * g.n_tiles + (uint64_t)t * kSub];   // walk records every 256 blocks
-    if (t_off + tile_bits > 8 * (fe - fo) || fe > terse_bytes) {      // chain / index inconsistent with the frame
+    if (fe > terse_bytes || fe <= fo || t_off > 8 * (fe - fo) || tile_bits > 8 * (fe - fo) - t_off) {   // chain / index inconsistent with the frame
         if (tid == 0) atomicMax(&status[0], 5u);
         return;
     }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __r
 }
 
 template <typename T>
-static hipError_t launch_decode_fast_t(const DecodeArgs& a, hipStream_t st) {
+static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hipStream_t st) {
     const FrameGeom g = a.geom;
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
     const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
@@ -345,8 +345,9 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, hipStream_t st) {
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                       a.frame_offsets, g, max_w, a.widths, a.tile_off, a.status);
+    if (!have_index)
+        hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, g, max_w, a.widths, a.tile_off, a.status);
     prof.mark(st);
     hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
                        (uint64_t)a.terse_bytes, a.frame_offsets, g, tpf, a.widths, a.tile_off,
@@ -356,14 +357,24 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, hipStream_t st) {
 }
 
 // Fast path preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned.
-hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, hipStream_t st) {
+hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
+    if (clear_status) {
+        hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, a.status);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st) {
     switch (dtype) {
-    case 0: return launch_decode_fast_t<uint8_t>(a, st);
-    case 1: return launch_decode_fast_t<int8_t>(a, st);
-    case 2: return launch_decode_fast_t<uint16_t>(a, st);
-    case 3: return launch_decode_fast_t<int16_t>(a, st);
-    case 4: return launch_decode_fast_t<uint32_t>(a, st);
-    case 5: return launch_decode_fast_t<int32_t>(a, st);
+    case 0: return launch_decode_fast_t<uint8_t>(a, have_index, st);
+    case 1: return launch_decode_fast_t<int8_t>(a, have_index, st);
+    case 2: return launch_decode_fast_t<uint16_t>(a, have_index, st);
+    case 3: return launch_decode_fast_t<int16_t>(a, have_index, st);
+    case 4: return launch_decode_fast_t<uint32_t>(a, have_index, st);
+    case 5: return launch_decode_fast_t<int32_t>(a, have_index, st);
     }
     return hipErrorInvalidValue;
 }

@@ -255,6 +255,8 @@ struct FusedArgs {
     uint64_t* frame_offsets;       // [F + 1]    output
     uint32_t* out32;
     uint32_t* status;
+    uint8_t* idx_widths;           // optional decode index (see include/trpx_hip.h): width of every block
+    uint64_t* idx_group_off;       //   and frame-relative bit offset of every 256-block group
     uint32_t debug;                // timing experiments only: 1 = no look-back waits, 2 = no tail wait (output invalid),
                                    // 4 = write s_memrealtime stamps (diagnostic build of the run, never timed)
     uint64_t* stamps;              // [tiles][8]
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
     for (int r = 0; r < kSub; ++r) {
         w[r] = nb[r] ? raw_width<T>(v[r]) : 0u;
         wmax = w[r] > wmax ? w[r] : wmax;
+        if (a.idx_widths && nb[r]) a.idx_widths[(uint64_t)frame * g.n_blocks + b0 + r * kThreads + tid] = (uint8_t)w[r];
         up[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[r], 0x138, 0xf, 0xf, false);   // wave_shr:1
         len[r] = nb[r] ? (lane ? header_len(w[r], up[r]) : 0u) + (uint32_t)nb[r] * w[r] : 0u;
         inc[r] = wave_inclusive_scan(len[r]);
@@ -446,6 +449,12 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
         if (tid == 0) atomicMax(&a.status[0], 7u);                       // look-back timeout
         return;
     }
+    if (a.idx_group_off && tid < (uint32_t)kSub && b0 + tid * kThreads < g.n_blocks) {
+        uint32_t rbv = 0;
+#pragma unroll
+        for (int r = 0; r < kSub; ++r) rbv = tid == (uint32_t)r ? rb[r] : rbv;
+        a.idx_group_off[(uint64_t)frame * g.n_tiles + (uint64_t)t * kSub + tid] = excl_bits + rbv;
+    }
     const uint64_t p0 = 8 * base_bytes + excl_bits;                      // absolute bit of the tile's first bit
     // bits this tile must materialise: its blocks, plus the frame's pad up to the byte S_f
     const uint64_t p_end = last_tile_of_frame ? 8 * (base_bytes + frame_size) : p0 + tile_total;
@@ -528,6 +537,8 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     a.frame_offsets = e.frame_offsets;
     a.out32 = reinterpret_cast<uint32_t*>(e.out);
     a.status = e.status;
+    a.idx_widths = e.idx_widths;
+    a.idx_group_off = e.idx_group_off;
     a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (2 * tiles + e.n_frames), 256));
     a.debug = getenv("TRPX_FUSED_DEBUG") ? (uint32_t)atoi(getenv("TRPX_FUSED_DEBUG")) : 0u;
     Profiler& prof = profiler();

@@ -19,6 +19,9 @@ struct EncodeArgs {
     uint64_t*   frame_size;    // n_frames
     uint64_t*   tile_off;      // n_frames * n_tiles
     uint32_t*   tile_bits;     // n_frames * n_tiles
+    // optional decode index (NULL = not wanted): what the header walk would produce
+    uint8_t*    idx_widths;    // n_frames * n_blocks
+    uint64_t*   idx_group_off; // n_frames * n_tiles (frame-relative bit offset of every 256-block group)
 };
 
 struct DecodeArgs {
@@ -41,7 +44,9 @@ size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStream_t st);
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
 // tuned decode (decode_fast.hip): needs frame offsets, n_values % 4 == 0 and 16-byte aligned pixels_out
-hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, hipStream_t st);
+hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st);
+// header walk only (fills a.widths / a.tile_off from the stream): builds the decode index of an existing stack
+hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 hipError_t launch_synth(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
                         void* out, hipStream_t st);
