@@ -31,7 +31,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s
 N_VALUES = 512 * 512
 FRAMES_PER_GPU = 2000
 ENC_STAGES_TWOPASS = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
-ENC_STAGES_FUSED = ["memset", "encode_fused"]
+ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
 DEC_STAGES = ["walk", "unpack"]
 
 
@@ -190,7 +190,7 @@ def main():
         for _ in range(reps):
             codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
             n = L.trpx_profile_read(buf, 8)
-            names = ENC_STAGES_FUSED if n == 2 else ENC_STAGES_TWOPASS
+            names = ENC_STAGES_FUSED if n == 3 else ENC_STAGES_TWOPASS
             for k in range(n):
                 stage[names[k]].append(buf[k])
             codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)

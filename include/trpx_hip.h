@@ -78,7 +78,7 @@ size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, 
  *   pixels        DEVICE  const T[n_frames * n_values], 16-byte aligned
  *   out           DEVICE  uint8_t[out_capacity], 16-byte aligned; receives sum(S_f) bytes
  *   frame_offsets DEVICE  uint64_t[n_frames + 1]; [k] = first byte of frame k, [n_frames] = total
- *   status        DEVICE  uint32_t[TRPX_STATUS_WORDS] (see above); word 1 = prolix_bits
+ *   status        DEVICE  uint32_t[TRPX_STATUS_WORDS], 8-byte aligned (see above); word 1 = prolix_bits
  *   workspace     DEVICE  >= trpx_encode_workspace_bytes(...), 16-byte aligned
  *
  * If the stack does not fit out_capacity, frame_offsets is still valid, status[0] =

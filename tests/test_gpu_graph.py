@@ -1,0 +1,48 @@
+"""GPU test: the device entry points only enqueue work (no allocation, no host sync) -- they can be captured
+into a HIP graph and replayed (include/trpx_hip.h conventions)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_encode_decode_capture_into_hip_graph(gpu):
+    import torch
+    from trpx_amd import codec, _lib
+    n, frames = 512 * 512, 64
+    px = codec.synth(np.uint16, 0, frames, n, device=gpu)
+    ws_e, ws_d = codec.Workspace(gpu), codec.Workspace(gpu)
+    cap = (frames * codec.worst_case_bytes(np.uint16, n) + 15) // 16 * 16
+    out = torch.empty(cap, dtype=torch.uint8, device=gpu)
+    offs = torch.empty(frames + 1, dtype=torch.int64, device=gpu)
+    st_e = torch.empty(8, dtype=torch.int32, device=gpu)
+    st_d = torch.empty(8, dtype=torch.int32, device=gpu)
+    back = torch.empty((frames, n), dtype=torch.uint16, device=gpu)
+    L = _lib.lib()
+    ws_e.get(L.trpx_encode_workspace_bytes(_lib.U16, n, frames, 12))
+    ws_d.get(L.trpx_decode_workspace_bytes(_lib.U16, n, frames, 12))
+    # eager reference run
+    codec.encode(px, out=out, workspace=ws_e, frame_offsets=offs, status=st_e)
+    torch.cuda.synchronize()
+    want = out[: int(offs[-1].item())].clone()
+    want_offs = offs.clone()
+    # capture encode + decode, replay on new pixels
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            codec.encode(px, out=out, workspace=ws_e, frame_offsets=offs, status=st_e)
+            codec.decode(out, offs, n, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
+    out.zero_(); offs.zero_(); back.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(st_e[0].item()) == 0 and int(st_d[0].item()) == 0
+    assert torch.equal(offs, want_offs) and torch.equal(out[: want.numel()], want)
+    assert torch.equal(back.view(torch.int16), px.view(torch.int16))
+    px.copy_(codec.synth(np.uint16, 500, frames, n, device=gpu))           # new data, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = codec.encode(px)
+    torch.cuda.synchronize()
+    assert torch.equal(offs, fresh.frame_offsets) and torch.equal(out[: fresh.total_bytes()], fresh.stack())
+    assert torch.equal(back.view(torch.int16), px.view(torch.int16))

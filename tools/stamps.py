@@ -18,7 +18,7 @@ tiles = frames * tpf
 # workspace layout (api.hip enc_ws): [two-pass arrays][fused descriptors][stamps]
 t256 = frames * ((21846 + 255) // 256)
 fused_off = ((((8 * frames + 15) // 16 * 16) + 8 * t256 + 15) // 16 * 16 + 4 * t256 + 255) // 256 * 256
-stamp_off = fused_off + (8 * (2 * tiles + frames) + 255) // 256 * 256
+stamp_off = fused_off + (8 * (3 * tiles + frames) + 255) // 256 * 256
 st = ws.buf[stamp_off: stamp_off + 64 * tiles].view(torch.int64).cpu().numpy().reshape(tiles, 8)
 t0 = st[:, 0].min()
 us = (st[:, :6] - t0) / 100.0

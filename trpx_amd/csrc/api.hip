@@ -154,7 +154,7 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     if (!pixels || !frame_offsets || !status || !workspace || (!out && out_capacity))
         return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: null pointer");
     if (((uintptr_t)out | (uintptr_t)workspace | (uintptr_t)frame_offsets) % 8 || (uintptr_t)out % 16 ||
-        (uintptr_t)status % 4 || (uintptr_t)pixels % trpx_dtype_size(dtype))
+        (uintptr_t)status % 8 || (uintptr_t)pixels % trpx_dtype_size(dtype))
         return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: misaligned pointer (out needs 16 B, workspace/offsets 8 B)");
     const EncWs w = enc_ws(g, n_frames);
     if (workspace_bytes < w.total)
@@ -200,7 +200,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: bad sizes");
     if (!terse || !pixels_out || !status || !workspace) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: null pointer");
-    if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 ||
+    if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8 ||
         (uintptr_t)pixels_out % trpx_dtype_size(out_dtype))
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: misaligned pointer (terse needs 4 B, workspace 8 B)");
     const DecWs w = dec_ws(g, n_frames);
@@ -235,7 +235,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !n_frames || !terse_bytes)
         return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG, "trpx_build_index: bad dtype/sizes/block");
     if (!terse || !frame_offsets || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: null pointer");
-    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8)
+    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: misaligned pointer");
     if (8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) >= 0xF0000000ull)
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: frames of >= 2^32 bits");
@@ -271,7 +271,7 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     if (!terse || !pixels_out || !status || !index || !frame_offsets)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: null pointer");
     if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 || (uintptr_t)pixels_out % 16 ||
-        n_values % 4)
+        (uintptr_t)status % 8 || n_values % 4)
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: needs n_values %% 4 == 0, 16-byte aligned pixels_out/index");
     const IdxLayout il = idx_layout(g, n_frames);
     trpx::DecodeArgs a{};

@@ -106,6 +106,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     return base + inc - v;
 }
 
+// ---- clearing device words on the launch stream ------------------------------------------------
+// Every call clears its status block (and the encoder its descriptor words) with this kernel instead of
+// hipMemsetAsync: kernel nodes replay reliably when the call is captured into a hipGraph, memset nodes did
+// not (ROCm 7.2 / torch 2.10: from the second replay on the words stayed uncleared; tests/test_gpu_graph.py).
+template <int kUnused = 0>
+__global__ __launch_bounds__(kThreads) void k_zero_words(uint64_t* __restrict__ p, uint64_t n, uint64_t* __restrict__ q,
+                                                         uint64_t m) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) p[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x < m) q[threadIdx.x] = 0ull;
+}
+inline void zero_status(uint32_t* status, hipStream_t st) {           // 8 x u32, 8-byte aligned
+    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, static_cast<uint64_t*>(nullptr), (uint64_t)0,
+                       reinterpret_cast<uint64_t*>(status), (uint64_t)4);
+}
+
 // ---- workspace layouts (device memory, carved by the host API) -------------------------------
 // encode: [status-shadow 64 B][frame_size u64 x F][tile_off u64 x F*T][tile_bits u32 x F*T]
 // decode: [tile_off u64 x F*T][widths u8 x F*nblocks (padded to 16)]

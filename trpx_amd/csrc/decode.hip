@@ -234,8 +234,7 @@ static hipError_t launch_decode_t(const DecodeArgs& a, bool have_offsets, hipStr
     const uint64_t n_tiles_total = (uint64_t)a.n_frames * g.n_tiles;
     const bool vec = (g.n_values % 4 == 0) && ((uintptr_t)a.pixels_out % 16 == 0);
     const uint32_t max_w = PixelTraits<T>::bits;
-    hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
-    if (e != hipSuccess) return e;
+    zero_status(a.status, st);
     const uint64_t* offs = a.frame_offsets;
     Profiler& prof = profiler();
     prof.begin();
@@ -260,8 +259,7 @@ static hipError_t launch_decode_t(const DecodeArgs& a, bool have_offsets, hipStr
 
 // Serial frame location only (no pixels): fills a.walk_offsets[0..n_frames].
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
-    if (e != hipSuccess) return e;
+    zero_status(a.status, st);
     hipLaunchKernelGGL(k_walk_serial, dim3(1), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.n_frames,
                        a.geom, max_w, a.widths, a.tile_off, a.walk_offsets, a.status);
     return hipGetLastError();

@@ -340,8 +340,7 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hip
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
     const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
     const uint32_t max_w = PixelTraits<T>::bits;
-    hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
-    if (e != hipSuccess) return e;
+    zero_status(a.status, st);
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
@@ -359,8 +358,7 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hip
 // Fast path preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned.
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
     if (clear_status) {
-        hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
-        if (e != hipSuccess) return e;
+        zero_status(a.status, st);
     }
     hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, a.status);

@@ -333,8 +333,7 @@ static hipError_t launch_encode_t(const EncodeArgs& a, hipStream_t st) {
     uint32_t* out32 = reinterpret_cast<uint32_t*>(a.out);
     const dim3 grid((uint32_t)n_tiles_total), blk(kThreads);
 
-    hipError_t e = hipMemsetAsync(a.status, 0, sizeof(uint32_t) * 8, st);
-    if (e != hipSuccess) return e;
+    zero_status(a.status, st);
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);

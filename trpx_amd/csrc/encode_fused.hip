@@ -35,7 +35,17 @@ namespace trpx {
 template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
 constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seconds), then give up
 
+// Diagnostics (tools/stamps.py, tools/enc_time.py): only in builds with -DTRPX_DIAGNOSTICS; the product build folds
+// every `diag(a) & x` test to false.  Bits: 1 = skip the look-back waits, 2 = skip the tail wait (both give WRONG
+// output, timing experiments only), 4 = write s_memrealtime stamps per tile.
+#ifdef TRPX_DIAGNOSTICS
+#define TRPX_DIAG(a) ((a).debug)
+#else
+#define TRPX_DIAG(a) 0u
+#endif
+
 constexpr uint64_t kStInvalid = 0, kStAgg = 1, kStPrefix = 2;
+constexpr uint64_t kHeadFlag = 1ull << 63, kTailFlag = 1ull << 62;   // boundary exchange words (k_encode_fused's end, k_stitch)
 __device__ __forceinline__ uint64_t make_desc(uint64_t st, uint64_t v) { return (st << 62) | (v & ((1ull << 62) - 1)); }
 __device__ __forceinline__ uint64_t desc_status(uint64_t d) { return d >> 62; }
 __device__ __forceinline__ uint64_t desc_value(uint64_t d) { return d & ((1ull << 62) - 1); }
@@ -250,15 +260,15 @@ struct FusedArgs {
     uint32_t tiles_per_frame;      // ceil(n_blocks / (sub_tiles * 256))
     uint64_t out_capacity;
     uint64_t* tile_desc;           // [F * tpf]  AGG: tile bits, PREFIX: inclusive bits inside the frame
-    uint64_t* tail_desc;           // [F * tpf]  READY(1): partial last dword of the tile
+    uint64_t* tail_desc;           // [F * tpf]  exchange word of the boundary between tile-1 and tile (see the kernel's end)
+    uint64_t* bnd_pos;             // [F * tpf]  output dword index of the boundary's shared dword (head side writes it)
     uint64_t* frame_desc;          // [F]        AGG: S_f bytes, PREFIX: inclusive bytes
     uint64_t* frame_offsets;       // [F + 1]    output
     uint32_t* out32;
     uint32_t* status;
     uint8_t* idx_widths;           // optional decode index (see include/trpx_hip.h): width of every block
     uint64_t* idx_group_off;       //   and frame-relative bit offset of every 256-block group
-    uint32_t debug;                // timing experiments only: 1 = no look-back waits, 2 = no tail wait (output invalid),
-                                   // 4 = write s_memrealtime stamps (diagnostic build of the run, never timed)
+    uint32_t debug;                // TRPX_DIAGNOSTICS builds only (see TRPX_DIAG)
     uint64_t* stamps;              // [tiles][8]
 };
 
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
     __shared__ uint32_t s_abort;
 
     const uint32_t tid = threadIdx.x;
-#define TRPX_STAMP(slot) do { if ((a.debug & 4u) && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TRPX_STAMP(slot) do { if ((TRPX_DIAG(a) & 4u) && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TRPX_STAMP(0);
     const int lane = lane_id(), wave = wave_id();
     const FrameGeom g = a.g;
@@ -316,14 +326,26 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
     // Lanes 1..63 get the previous block's width from their neighbour; lane 0's header depends on the
     // previous wavefront's last width, so it is left out of the scan here and added after barrier #1.
     uint32_t wmax = 0;
+    uint32_t hlr[kSub];                  // header length of lanes 1..63 (lane 0: fixed up after barrier #1)
 #pragma unroll
     for (int r = 0; r < kSub; ++r) {
         w[r] = nb[r] ? raw_width<T>(v[r]) : 0u;
         wmax = w[r] > wmax ? w[r] : wmax;
         if (a.idx_widths && nb[r]) a.idx_widths[(uint64_t)frame * g.n_blocks + b0 + r * kThreads + tid] = (uint8_t)w[r];
         up[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[r], 0x138, 0xf, 0xf, false);   // wave_shr:1
-        len[r] = nb[r] ? (lane ? header_len(w[r], up[r]) : 0u) + (uint32_t)nb[r] * w[r] : 0u;
-        inc[r] = wave_inclusive_scan(len[r]);
+        hlr[r] = header_len(w[r], up[r]);
+        len[r] = nb[r] ? (lane ? hlr[r] : 0u) + (uint32_t)nb[r] * w[r] : 0u;
+    }
+    // wave scans, two rounds per 32-bit DPP scan: a wave's 64 blocks are < 2^16 bits (64 * 396 = 25 344)
+    static_assert(kWave * max_block_bits<T>() < 65536, "packed scan needs 16-bit wave totals");
+#pragma unroll
+    for (int r = 0; r < kSub; r += 2) {
+        const uint32_t two = wave_inclusive_scan(len[r] | (len[r + 1] << 16));
+        inc[r] = two & 0xFFFFu;
+        inc[r + 1] = two >> 16;
+    }
+#pragma unroll
+    for (int r = 0; r < kSub; ++r) {
         const uint32_t w_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[r]);
         const uint32_t v_first = (uint32_t)__builtin_amdgcn_readfirstlane(nb[r]);
         if (lane == 63) {
@@ -350,20 +372,22 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
         const uint32_t incl = wave_inclusive_scan(tot);
         const uint32_t excl = incl - tot;
         const uint32_t hw = h0 | (wprev << 8);
+        const int swave = __builtin_amdgcn_readfirstlane(wave);          // wave index as a scalar: v_readlane, no LDS shuffle
 #pragma unroll
         for (int r = 0; r < kSub; ++r) {
             rb[r] = (uint32_t)__builtin_amdgcn_readlane((int)excl, r * 4);
-            const uint32_t pb = (uint32_t)__shfl((int)excl, r * 4 + wave, 64);
-            const uint32_t ph = (uint32_t)__shfl((int)hw, r * 4 + wave, 64);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)excl, r * 4 + swave);
+            const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)hw, r * 4 + swave);
             off[r] = pb + (lane ? (ph & 0xFFu) : 0u) + inc[r] - len[r];
             wp[r] = lane ? up[r] : ph >> 8;
+            hlr[r] = lane ? hlr[r] : (ph & 0xFFu);                       // lane 0's header length from the fix-up
         }
         rb[kSub] = (uint32_t)__builtin_amdgcn_readlane((int)incl, kSub * 4 - 1);
     }
     const uint32_t tile_total = rb[kSub];
 
     // publish this tile's bit count at once (decoupled look-back: nobody waits for our look-back)
-    if (tid == 0 && !(a.debug & 1u))
+    if (tid == 0 && !(TRPX_DIAG(a) & 1u))
         st_desc(a.tile_desc + tile, make_desc(t == 0 ? kStPrefix : kStAgg, tile_total));
     // d_prolix_bits (Terse.hpp:516): read first, ~every wave sees a value that is already >= its own
     if (wmax && lane == 0 && wmax > __hip_atomic_load(&a.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -373,7 +397,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
     // publishes.  All other tiles pack first (their look-back is then usually satisfied at the first poll).
     uint64_t early_excl = 0;
     bool early_ok = true;
-    if (last_tile_of_frame && wave == 0 && t != 0 && !(a.debug & 1u)) {
+    if (last_tile_of_frame && wave == 0 && t != 0 && !(TRPX_DIAG(a) & 1u)) {
         early_ok = lookback(a.tile_desc, (int64_t)tile, (int64_t)(tile - t), &early_excl);
         if (early_ok && lane == 0) {
             st_desc(a.tile_desc + tile, make_desc(kStPrefix, early_excl + tile_total));
@@ -386,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
 #pragma unroll
         for (int r = 0; r < kSub; ++r) {
             const uint32_t pos = off[r];
-            const uint32_t hl = header_len(w[r], wp[r]);
+            const uint32_t hl = hlr[r];                                  // (lane 0: from the piece fix-up)
 #ifndef TRPX_ABLATE
 #define TRPX_ABLATE 0
 #endif
@@ -413,7 +437,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
         if (wave == 0) {
             uint64_t excl = 0;
             bool ok = true;
-            if (a.debug & 1u) excl = (uint64_t)t * 40000u;
+            if (TRPX_DIAG(a) & 1u) excl = (uint64_t)t * 40000u;
             else if (last_tile_of_frame) {
                 excl = early_excl;
                 ok = early_ok;
@@ -428,7 +452,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
         } else if (wave == 1) {
             uint64_t base = 0;
             bool ok = true;
-            if (a.debug & 1u) base = (uint64_t)frame * 120000u;
+            if (TRPX_DIAG(a) & 1u) base = (uint64_t)frame * 120000u;
             else ok = lookback(a.frame_desc, (int64_t)frame, 0, &base);
             if (lane == 0) { s_base_bytes = base; if (!ok) s_abort = 1; }
         }
@@ -463,53 +487,54 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
     const bool head_pending = s0 != 0;                                   // first dword also holds the previous tile's bits
     const uint64_t d_first = p0 >> 5, d_last = p_end >> 5;
 
-    // ---- flush: global dword d_first + j = {image[k+1], image[k]} >> sh, k = j - (s0 != 0) -------------------
+    // ---- tile boundary dwords ---------------------------------------------------------------------------
+    // A dword that straddles two tiles (or frames) is written by nobody here: both sides OR their bits into the
+    // boundary's exchange word {bit 63: head side there, bit 62: tail side there, low 32: the bits} with a
+    // fire-and-forget atomic and the head side records the dword's index; k_stitch (a ~44 000-thread kernel
+    // right behind this one) stores the merged dwords.  Nothing in this kernel waits for another tile's data.
     const int32_t k_first = head_pending ? -1 : 0;
     const uint32_t n_out = (uint32_t)(d_last - d_first);
-    uint32_t head_keep = 0;
+    const bool completed_first = d_last > d_first;                       // tile finished at least its first dword
+    const bool is_last_tile = tile + 1 == (uint64_t)a.n_frames * a.tiles_per_frame;
+    if (tid == 0) {
+        const int32_t kt = k_first + (int32_t)n_out;
+        const uint32_t tail_bits = (p_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], kt >= 0 ? s_stage[kt] : 0u, sh) : 0u;
+        if (head_pending) {                                              // our share of dword d_first (a tile that does not
+            const uint32_t head_bits = __builtin_amdgcn_alignbit(s_stage[0], 0u, sh);   // complete it: all of its bits)
+            __hip_atomic_fetch_or(a.tail_desc + tile, kHeadFlag | head_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.bnd_pos[tile] = d_first;
+        }
+        if ((p_end & 31) != 0 && (completed_first || !head_pending)) {   // our share of dword d_last
+            if (is_last_tile) { if (writable) __builtin_nontemporal_store(tail_bits, a.out32 + d_last); }
+            else __hip_atomic_fetch_or(a.tail_desc + tile + 1, kTailFlag | tail_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---- flush: global dword d_first + j = {image[k+1], image[k]} >> sh, k = j - (s0 != 0) -------------------
     for (uint32_t j = tid; j < ((TRPX_ABLATE & 4) ? 0u : n_out); j += kThreads) {
+        if (j == 0 && head_pending) continue;                            // the shared first dword: k_stitch
         const int32_t k = k_first + (int32_t)j;
         const uint32_t lo = k >= 0 ? s_stage[k] : 0u, hi = s_stage[k + 1];
         const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, sh);
-        if (j == 0 && head_pending) head_keep = x;                       // completed below with the previous tile's tail
-        else if (writable) __builtin_nontemporal_store(x, a.out32 + d_first + j);
+        if (writable) __builtin_nontemporal_store(x, a.out32 + d_first + j);
     }
+    TRPX_STAMP(4);
+    TRPX_STAMP(5);
+    if ((TRPX_DIAG(a) & 4u) && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[blockIdx.x * 8 + 6] = xcc; }
+}
 
-    // ---- tile boundary dwords: tail hand-over ----------------------------------------------------------
-    if (tid == 0) {
-        const bool is_last_tile = tile + 1 == (uint64_t)a.n_frames * a.tiles_per_frame;
-        const int32_t kt = k_first + (int32_t)n_out;
-        const uint32_t tail_bits = (p_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], kt >= 0 ? s_stage[kt] : 0u, sh) : 0u;
-        const bool completed_first = d_last > d_first;                   // tile finished at least its first dword
-        // Publish the tail FIRST whenever it does not depend on the predecessor's: the hand-over is then
-        // never a serial chain through the tiles.
-        if (completed_first) {
-            if (is_last_tile) { if ((p_end & 31) != 0 && writable) __builtin_nontemporal_store(tail_bits, a.out32 + d_last); }
-            else st_desc(a.tail_desc + tile, make_desc(kStAgg, tail_bits));
-        }
-        TRPX_STAMP(4);
-        uint32_t pred_tail = 0;
-        bool ok = true;
-        if (head_pending && !(a.debug & 2u)) {                           // wait for tile-1's tail bits
-            uint32_t spins = 0;
-            uint64_t gd;
-            while (desc_status(gd = ld_desc(a.tail_desc + tile - 1)) == kStInvalid) {
-                if (++spins > kSpinLimit) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            pred_tail = (uint32_t)desc_value(gd);
-        }
-        if (!ok) atomicMax(&a.status[0], 7u);
-        TRPX_STAMP(5);
-        if (a.debug & 4u) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[blockIdx.x * 8 + 6] = xcc; }
-        if (completed_first) {
-            if (head_pending && writable) __builtin_nontemporal_store(head_keep | pred_tail, a.out32 + d_first);
-        } else {                                                         // whole tile inside one dword (tiny frames)
-            const uint32_t my_tail = tail_bits | pred_tail;
-            if (is_last_tile) { if ((p_end & 31) != 0 && writable) __builtin_nontemporal_store(my_tail, a.out32 + d_last); }
-            else st_desc(a.tail_desc + tile, make_desc(kStAgg, my_tail));
-        }
-    }
+// Stores every dword that two (or, with tiny tiles, more) tiles share: the OR of what they deposited.
+__global__ __launch_bounds__(kThreads) void k_stitch(const uint64_t* __restrict__ xw, const uint64_t* __restrict__ pos,
+                                                     uint64_t n_tiles, uint32_t* __restrict__ out32, uint64_t out_capacity) {
+    const uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x + 1;     // boundary b = between tile b-1 and tile b
+    if (b >= n_tiles) return;
+    const uint64_t w = xw[b];
+    if (!(w & kHeadFlag)) return;                                         // dword-aligned boundary: nothing shared
+    const uint64_t d = pos[b];
+    if ((xw[b - 1] & kHeadFlag) && pos[b - 1] == d && b > 1) return;      // middle of a run (tiny tiles): its first boundary stores
+    uint32_t acc = (uint32_t)w;
+    for (uint64_t k = b + 1; k < n_tiles && (xw[k] & kHeadFlag) && pos[k] == d; ++k) acc |= (uint32_t)xw[k];
+    if (4 * d + 4 <= out_capacity) out32[d] = acc;
 }
 
 template <typename T>
@@ -520,7 +545,7 @@ static uint32_t fused_tiles_per_frame(const FrameGeom& g) {
 
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     const size_t tpf = ((size_t)g.n_blocks + 2 * kThreads - 1) / (2 * kThreads);   // finest tiling (32-bit pixels)
-    return align_up(8 * (2 * n_frames * tpf + n_frames), 256) + 64 * n_frames * tpf;   // + diagnostic stamps
+    return align_up(8 * (3 * n_frames * tpf + n_frames), 256) + 64 * n_frames * tpf;   // + diagnostic stamps
 }
 
 template <typename T>
@@ -533,24 +558,33 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     const size_t tiles = (size_t)e.n_frames * a.tiles_per_frame;
     a.tile_desc = static_cast<uint64_t*>(ws);
     a.tail_desc = a.tile_desc + tiles;
-    a.frame_desc = a.tail_desc + tiles;
+    a.bnd_pos = a.tail_desc + tiles;
+    a.frame_desc = a.bnd_pos + tiles;
     a.frame_offsets = e.frame_offsets;
     a.out32 = reinterpret_cast<uint32_t*>(e.out);
     a.status = e.status;
     a.idx_widths = e.idx_widths;
     a.idx_group_off = e.idx_group_off;
-    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (2 * tiles + e.n_frames), 256));
+    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + e.n_frames), 256));
+#ifdef TRPX_DIAGNOSTICS
     a.debug = getenv("TRPX_FUSED_DEBUG") ? (uint32_t)atoi(getenv("TRPX_FUSED_DEBUG")) : 0u;
+#else
+    a.debug = 0u;
+#endif
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    hipError_t err = hipMemsetAsync(e.status, 0, sizeof(uint32_t) * 8, st);
-    if (err != hipSuccess) return err;
-    err = hipMemsetAsync(ws, 0, 8 * (2 * tiles + e.n_frames), st);      // every polled word, every call
-    if (err != hipSuccess) return err;
+    // every polled / OR-ed word and the status block, cleared on every call (see k_zero_words)
+    hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
+                       (uint64_t)(3 * tiles + e.n_frames), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
+    hipError_t err = hipSuccess;
     prof.mark(st);
     hipLaunchKernelGGL((k_encode_fused<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, st,
                        static_cast<const T*>(e.pixels), a);
+    prof.mark(st);
+    if (tiles > 1)
+        hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles - 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                           a.tail_desc, a.bnd_pos, (uint64_t)tiles, a.out32, (uint64_t)e.out_capacity);
     prof.mark(st);
     return hipGetLastError();
 }
