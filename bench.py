@@ -32,7 +32,8 @@ N_VALUES = 512 * 512
 FRAMES_PER_GPU = 2000
 ENC_STAGES_TWOPASS = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
 ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
-DEC_STAGES = ["walk", "unpack"]
+DEC_STAGES = ["walk", "unpack"]        # tiled decode (two kernels)
+DEC_STAGES_FRAMES = ["decode_frames"]  # one workgroup per frame (walk + extraction fused)
 
 
 def host_cores() -> int:
@@ -100,8 +101,13 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TRPX_BENCH_FORCE_DIST=1: run the RCCL code path (init, size gather, barrier) even with one rank (self test)
+    use_dist = world > 1 or os.environ.get("TRPX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from trpx_amd import codec, sharded, _lib
@@ -124,15 +130,15 @@ def main():
 
     def step():
         enc = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
-        if world > 1:   # per-frame size gather over xGMI -> global byte offsets of every frame
-            sharded.gather_global_offsets(offs, st_e[1:2], counts=[frames] * world)
+        if use_dist:    # per-frame size gather over xGMI -> global byte offsets of every frame
+            sharded.gather_global_offsets(offs, st_e[1:2], counts=[frames] * world, force=True)
         # decode straight from the device-resident stack (bounded by its worst-case capacity; the
         # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
         codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
         return enc
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +150,7 @@ def main():
         enc = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -185,7 +191,7 @@ def main():
         assert int(st_d[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
         # per-kernel durations: HIP events recorded by the library on the launch stream
         L.trpx_profile_enable(1)
-        stage = {n: [] for n in ENC_STAGES_TWOPASS + ENC_STAGES_FUSED + DEC_STAGES}
+        stage = {n: [] for n in ENC_STAGES_TWOPASS + ENC_STAGES_FUSED + DEC_STAGES + DEC_STAGES_FRAMES}
         buf = (C.c_float * 8)()
         for _ in range(reps):
             codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
@@ -195,8 +201,9 @@ def main():
                 stage[names[k]].append(buf[k])
             codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
             n = L.trpx_profile_read(buf, 8)
+            dnames = DEC_STAGES_FRAMES if n == 1 else DEC_STAGES
             for k in range(n):
-                stage[DEC_STAGES[k]].append(buf[k])
+                stage[dnames[k]].append(buf[k])
         L.trpx_profile_enable(0)
         stage_ms = {k: float(np.mean(v)) for k, v in stage.items() if v}
         pix_bytes = frames * N_VALUES * 2
@@ -250,7 +257,7 @@ def main():
             cores = host_cores()
             result["cpu_baseline"] = cpu_baseline(px.cpu().numpy(), cores)
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -219,9 +219,17 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
-    static const bool basic = getenv("TRPX_DECODE_PATH") && strcmp(getenv("TRPX_DECODE_PATH"), "basic") == 0;
+    // TRPX_DECODE_PATH = basic | tiles | frames forces one of the three decode paths (A/B checks)
+    static const char* dpath = getenv("TRPX_DECODE_PATH") ? getenv("TRPX_DECODE_PATH") : "";
+    static const bool basic = strcmp(dpath, "basic") == 0;
+    static const bool force_tiles = strcmp(dpath, "tiles") == 0, force_frames = strcmp(dpath, "frames") == 0;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
-    if (frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0)
+    const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0;
+    // many small frames: one workgroup per frame, the walk and the extraction overlap inside it;
+    // few large frames: the tiled kernels (the walk is then the whole critical path either way)
+    if (fast_ok && !force_tiles && (force_frames || n_frames >= 128))
+        HIP_TRY(trpx::launch_decode_frames(out_dtype, a, static_cast<hipStream_t>(stream)));
+    else if (fast_ok)
         HIP_TRY(trpx::launch_decode_fast(out_dtype, a, false, static_cast<hipStream_t>(stream)));
     else
         HIP_TRY(trpx::launch_decode(out_dtype, a, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));

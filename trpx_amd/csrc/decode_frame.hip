@@ -1,0 +1,244 @@
+// PROLIX decode, one workgroup per frame (gfx950 / CDNA4): the serial header walk and the parallel
+// field extraction run side by side inside the workgroup, coupled through LDS only.
+// Replaces jpa::Terse::prolix(Iterator, frame) (reference include/Terse.hpp:352-389) and
+// Bit_range::get_range / operator T() (Bit_pointer.hpp:742-792, :597-617).
+//
+//   wave 0 ("walker")    walks the frame's header chain (Terse.hpp:360-372) exactly like k_walk_lds --
+//                        64 candidate blocks per step, stream staged through a private LDS window --
+//                        but deposits width[b] and the 64-block group offsets in LDS instead of HBM.
+//   waves 1-3            one super-step (384 blocks = 6 groups) behind the walker: each wave takes two
+//                        groups, fetches the group's stream bytes (L2-hot: the walker has just read them),
+//                        extracts the 12 fields of every block with width-specialised code and stores
+//                        the pixels (24/48 bytes per lane, non-temporal).
+//   one barrier per super-step; width buffers are double buffered.
+//
+// The walk is the critical path (serial by construction of the format); the extraction hides under it.
+// HBM traffic per frame: S read (once from HBM, once more from L2) + N*sizeof(T) written = algorithmic.
+// Best for many small frames (one workgroup each); few huge frames are better served by the tiled
+// kernels of decode_fast.hip with a decode index.
+#include "codec_common.hpp"
+#include "encode_kernels.hpp"
+#include "profile.hpp"
+#include "unpack_common.hpp"
+
+namespace trpx {
+
+constexpr int kStepGroups = 6;                         // 64-block groups per super-step (2 per unpack wave)
+constexpr int kStepBlocks = kStepGroups * kWave;       // 384
+constexpr int kFrameChunkDw = 2048;                    // walker's stream window: 8 KB
+
+template <typename T>
+constexpr int group_image_dwords() { return (kWave * max_block_bits<T>() + 31) / 32 + 12; }
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 8) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+    constexpr int kGImg = group_image_dwords<T>();
+    constexpr uint32_t kMaxW = PixelTraits<T>::bits;
+    __shared__ uint32_t s_chunk[kFrameChunkDw + 4];    // walker's window of the stream
+    __shared__ uint32_t s_gimg[3][kGImg];              // one group image per unpack wave
+    __shared__ uint8_t s_w[2][kStepBlocks];            // widths of the super-step's blocks (double buffered)
+    __shared__ uint32_t s_goff[2][kStepGroups];        // frame-relative bit offset of each group's first block
+    __shared__ uint32_t s_whalo[2];                    // width of the block before the super-step
+    __shared__ uint32_t s_err;
+
+    const uint32_t lane = (uint32_t)lane_id();
+    const int wave = wave_id();
+    const uint64_t frame = blockIdx.x;
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    if (threadIdx.x == 0) s_err = (fe > fo && fe <= terse_bytes) ? 0u : 1u;
+    __syncthreads();
+    if (s_err) {
+        if (threadIdx.x == 0) atomicMax(&status[0], 5u);
+        return;
+    }
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(terse);
+    const uint64_t n_dw = (terse_bytes + 3) / 4;
+    const bool base16 = ((uintptr_t)terse & 15) == 0;
+    const uint64_t frame_abit = 8 * fo;
+    const uint32_t limit = (uint32_t)(8 * (fe - fo));
+    const uint64_t frame_dw = frame_abit >> 5;
+    const uint32_t frame_sh = (uint32_t)(frame_abit & 31);
+    const uint32_t n_blocks = g.n_blocks;
+    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(n_blocks - 1) * kBlock);
+    const uint32_t n_steps = (n_blocks + kStepBlocks - 1) / kStepBlocks;
+    T* __restrict__ fout = pixels_out + frame * g.n_values;
+
+    // walker state (wave 0 only; wave-uniform)
+    int32_t c_lo = 0, c_hi = 0;
+    uint32_t b = 0, w_prev = 0, pos = 0, final_pos = 0;
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);      // the walk is the critical path
+
+    for (uint32_t s = 0; s <= n_steps; ++s) {
+        if (wave == 0) {
+            if (s < n_steps) {
+                const uint32_t buf = s & 1u;
+                const uint32_t end_b = (s + 1) * kStepBlocks < n_blocks ? (s + 1) * kStepBlocks : n_blocks;
+                if (lane == 0) s_whalo[buf] = w_prev;
+                bool bad = false;
+                while (b < end_b) {
+                    const uint32_t stride = 1u + kBlock * w_prev;
+                    const uint32_t need_lo = (frame_sh + pos) >> 5;
+                    const uint32_t need_hi = ((frame_sh + pos + 63u * stride) >> 5) + 2;
+                    if ((int32_t)need_lo < c_lo || (int32_t)need_hi > c_hi) {       // refill the window
+                        c_lo = (int32_t)(((frame_dw + need_lo) & ~3ull) - frame_dw);
+                        c_hi = c_lo + kFrameChunkDw;
+                        const uint64_t d0 = (uint64_t)((int64_t)frame_dw + c_lo);
+                        if (base16 && (d0 & 3) == 0 && d0 + kFrameChunkDw <= n_dw) {
+                            constexpr int kIt = kFrameChunkDw / (kWave * 4);
+                            uint4 x[kIt];
+#pragma unroll
+                            for (int it = 0; it < kIt; ++it) x[it] = *reinterpret_cast<const uint4*>(s32 + d0 + it * kWave * 4 + lane * 4);
+#pragma unroll
+                            for (int it = 0; it < kIt; ++it) *reinterpret_cast<uint4*>(&s_chunk[it * kWave * 4 + lane * 4]) = x[it];
+                        } else {
+                            for (uint32_t i = lane * 4; i < (uint32_t)kFrameChunkDw; i += kWave * 4) {
+                                const uint64_t d = d0 + i;
+                                uint4 x;
+                                x.x = d < n_dw ? s32[d] : 0u; x.y = d + 1 < n_dw ? s32[d + 1] : 0u;
+                                x.z = d + 2 < n_dw ? s32[d + 2] : 0u; x.w = d + 3 < n_dw ? s32[d + 3] : 0u;
+                                *reinterpret_cast<uint4*>(&s_chunk[i]) = x;
+                            }
+                        }
+                    }
+                    const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;
+                    const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
+                    const uint32_t left = end_b - b;                                  // candidates inside this super-step
+                    const uint64_t valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+                    const uint64_t same = __ballot((bits & 1u) != 0u) & valid;        // Terse.hpp:361
+                    const uint64_t stop = ~same;
+                    const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                    uint32_t e_w = w_prev, new_pos, new_b;
+                    if (first < left && first < 64u) {                                // explicit header at block b + first
+                        const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, first);
+                        uint32_t w = (eb >> 1) & 7u, hl = 4;                          // Terse.hpp:362-370
+                        if (w == 7u) {
+                            w += (eb >> 4) & 3u; hl = 6;
+                            if (w == 10u) { w += (eb >> 6) & 63u; hl = 12; }
+                        }
+                        if (w > kMaxW) { bad = true; break; }
+                        e_w = w;
+                        const uint32_t nbv = b + first + 1 == n_blocks ? nb_last : (uint32_t)kBlock;
+                        new_pos = pos + first * stride + hl + nbv * w;
+                        new_b = b + first + 1;
+                        if (new_b == n_blocks) final_pos = new_pos;
+                    } else {                                                          // the rest of the window repeats w_prev
+                        const uint32_t cnt = left < 64u ? left : 64u;
+                        if (b + cnt == n_blocks) final_pos = pos + (cnt - 1) * stride + 1u + nb_last * w_prev;
+                        new_pos = pos + cnt * stride;
+                        new_b = b + cnt;
+                    }
+                    const uint32_t n_done = new_b - b, rel = b - s * kStepBlocks;
+                    if (lane < n_done) {
+                        s_w[buf][rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
+                        if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + lane * stride;
+                    }
+                    pos = new_pos;
+                    w_prev = e_w;
+                    b = new_b;
+                    if (pos > limit + 64u * 400u) { bad = true; break; }              // ran away: corrupt stream
+                }
+                if (!bad && b == n_blocks)                                            // S_f = 1 + bits/8 (Terse.hpp:547)
+                    bad = !(final_pos <= limit && 1 + (uint64_t)final_pos / 8 == fe - fo);
+                if (bad && lane == 0) s_err = 1u;
+            }
+        } else if (s >= 1) {
+            // ---- unpack super-step s-1: this wave's two groups, one after the other ------------------------------
+            // (fetching both groups first needs a second set of per-lane state: 64+ VGPRs, spills, measured slower)
+            const uint32_t pbuf = (s - 1) & 1u;
+            uint32_t* __restrict__ img = s_gimg[wave - 1];
+#pragma unroll 1
+            for (int gq = 0; gq < 2; ++gq) {
+                const uint32_t gi = (uint32_t)(wave - 1) * 2u + gq;
+                const uint32_t rel = gi * kWave + lane;
+                const uint32_t blk = (s - 1) * kStepBlocks + rel;
+                if ((s - 1) * kStepBlocks + gi * kWave >= n_blocks) break;            // wave-uniform: group past the frame's end
+                uint32_t w = 0, hl = 0;
+                int nb = 0;
+                if (blk < n_blocks) {
+                    w = s_w[pbuf][rel];
+                    const uint32_t wp = rel ? s_w[pbuf][rel - 1] : s_whalo[pbuf];
+                    hl = header_len(w, wp);
+                    nb = blk + 1 == n_blocks ? (int)nb_last : kBlock;
+                }
+                const uint32_t len = nb ? hl + (uint32_t)nb * w : 0u;
+                const uint32_t inc = wave_inclusive_scan(len);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                const uint64_t a0 = frame_abit + s_goff[pbuf][gi];                    // absolute bit of the group's first bit
+                const uint64_t d_lo = (a0 >> 5) & ~3ull;
+                const uint32_t n_need = (uint32_t)(((a0 + total + 31) >> 5) - d_lo) + 1;
+                for (uint32_t i = lane * 4; i < n_need && i < (uint32_t)kGImg - 4; i += kWave * 4) {
+                    const uint64_t d = d_lo + i;
+                    uint4 x;
+                    if (base16 && d + 4 <= n_dw) x = *reinterpret_cast<const uint4*>(s32 + d);
+                    else {
+                        x.x = d < n_dw ? s32[d] : 0u; x.y = d + 1 < n_dw ? s32[d + 1] : 0u;
+                        x.z = d + 2 < n_dw ? s32[d + 2] : 0u; x.w = d + 3 < n_dw ? s32[d + 3] : 0u;
+                    }
+                    *reinterpret_cast<uint4*>(&img[i]) = x;
+                }
+                const uint32_t q = (uint32_t)(a0 - 32 * d_lo) + (inc - len) + hl;     // first payload bit in the image
+                uint32_t u[kBlock];
+#pragma unroll
+                for (int k = 0; k < kBlock; ++k) u[k] = 0u;                            // w == 0 -> zeros (Terse.hpp:373-374)
+                uint64_t todo = __ballot(nb == kBlock && w != 0u);
+                while (todo) {
+                    const int l0 = __builtin_ctzll(todo);
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                    const bool mine = nb == kBlock && w == w0;
+                    uint32_t qq = q;
+                    asm volatile("" : "+v"(qq));                                      // keep the specialised bodies out of LICM's reach
+                    if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(img, qq, w0, u);
+                    todo &= ~__ballot(mine);
+                }
+                if (nb == kBlock) store_block<T>(fout + (uint64_t)blk * kBlock, u);
+                else if (nb) {                                                        // the frame's last, partial block
+                    const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+                    uint32_t p = q;
+                    for (int k = 0; k < nb; ++k) {
+                        uint32_t f = 0;
+                        if (w) {
+                            const uint64_t two = (uint64_t)img[p >> 5] | ((uint64_t)img[(p >> 5) + 1] << 32);
+                            f = (uint32_t)(two >> (p & 31u)) & mask;
+                            if (PixelTraits<T>::is_signed) f = (uint32_t)((int32_t)(f << (32u - w)) >> (32u - w));
+                        }
+                        fout[(uint64_t)blk * kBlock + k] = (T)f;
+                        p += w;
+                    }
+                }
+            }
+        }
+        __syncthreads();                               // super-step boundary: widths of step s published, step s-1 consumed
+        if (s_err) break;
+    }
+    if (s_err && threadIdx.x == 0) atomicMax(&status[0], 5u);              // TRPX_ERR_CORRUPT
+}
+
+template <typename T>
+static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
+    zero_status(a.status, st);
+    Profiler& prof = profiler();
+    prof.begin();
+    prof.mark(st);
+    hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status);
+    prof.mark(st);
+    return hipGetLastError();
+}
+
+// Preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned,
+// frames of < 2^32 bits.
+hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_decode_frames_t<uint8_t>(a, st);
+    case 1: return launch_decode_frames_t<int8_t>(a, st);
+    case 2: return launch_decode_frames_t<uint16_t>(a, st);
+    case 3: return launch_decode_frames_t<int16_t>(a, st);
+    case 4: return launch_decode_frames_t<uint32_t>(a, st);
+    case 5: return launch_decode_frames_t<int32_t>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace trpx

@@ -45,6 +45,8 @@ hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStre
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
 // tuned decode (decode_fast.hip): needs frame offsets, n_values % 4 == 0 and 16-byte aligned pixels_out
 hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st);
+// one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames
+hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
 // header walk only (fills a.widths / a.tile_off from the stream): builds the decode index of an existing stack
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);

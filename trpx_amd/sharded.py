@@ -18,7 +18,7 @@ def frame_range(n_frames_total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.Tensor | None = None,
-                          group=None, counts: list[int] | None = None):
+                          group=None, counts: list[int] | None = None, force: bool = False):
     """All-gather the per-frame sizes of every rank and prefix-sum them.
 
     local_offsets: int64 [f_local + 1] (byte offsets of the local stack, as trpx_encode writes them).
@@ -28,7 +28,7 @@ def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     sizes = local_offsets[1:] - local_offsets[:-1]
-    if world == 1:
+    if world == 1 and not force:   # (force: run the collective even alone -- self test of the RCCL path)
         pb = local_prolix_bits.max() if local_prolix_bits is not None else None
         return local_offsets.clone(), torch.zeros((), dtype=torch.int64, device=local_offsets.device), pb
     if counts is not None:                                  # shard sizes known up front: no host round trip
