@@ -56,7 +56,7 @@ def cpu_baseline(px_host: np.ndarray, cores: int):
     chunks = [px_host[i::cores] for i in range(cores)]
     chunks = [np.ascontiguousarray(c) for c in chunks if c.shape[0]]
 
-    reps = 6          # ~2000 frames x 6 passes x ~0.4 ms x 2 (enc+dec) = ~10-15 CPU-seconds in total
+    reps = 20         # 2000 frames x 20 passes x ~0.4 ms (enc+dec) = ~16-20 CPU-seconds in total
 
     def run(c, n=reps):
         tot = dict(enc_s=0.0, dec_s=0.0, bytes=0, ok=True)

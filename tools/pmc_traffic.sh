@@ -18,6 +18,6 @@ def load(d):
     return acc
 for d in ("cal_fetch","cal_write","enc_fetch","enc_write"):
     for (k,c),v in sorted(load(d).items()):
-        if any(x in k for x in ("read16","read24","copy16","k_encode_fused","k_walk_lds","k_unpack_tiles","k_synth")):
+        if any(x in k for x in ("read16","read24","copy16","k_encode_fused","k_stitch","k_zero_words","k_walk_lds","k_unpack_tiles","k_decode_frames","k_synth")):
             print(f"{d:10s} {k:62s} {c:11s} n={len(v):3d} mean={sum(v)/len(v):16.1f} min={min(v):16.1f}")
 PY
