@@ -23,7 +23,7 @@
 
 namespace trpx {
 
-constexpr int kStepGroups = 6;                         // 64-block groups per super-step (2 per unpack wave)
+constexpr int kStepGroups = 12;                        // 64-block groups per super-step (kStepGroups / 3 per unpack wave)
 constexpr int kStepBlocks = kStepGroups * kWave;       // 384
 constexpr int kFrameChunkDw = 2048;                    // walker's stream window: 8 KB
 
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_decode_frames(const uint8_t* __
             const uint32_t pbuf = (s - 1) & 1u;
             uint32_t* __restrict__ img = s_gimg[wave - 1];
 #pragma unroll 1
-            for (int gq = 0; gq < 2; ++gq) {
-                const uint32_t gi = (uint32_t)(wave - 1) * 2u + gq;
+            for (int gq = 0; gq < kStepGroups / 3; ++gq) {
+                const uint32_t gi = (uint32_t)(wave - 1) * (uint32_t)(kStepGroups / 3) + gq;
                 const uint32_t rel = gi * kWave + lane;
                 const uint32_t blk = (s - 1) * kStepBlocks + rel;
                 if ((s - 1) * kStepBlocks + gi * kWave >= n_blocks) break;            // wave-uniform: group past the frame's end

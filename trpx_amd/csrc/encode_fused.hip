@@ -4,8 +4,9 @@
 // pack primitives (Bit_range::append_range :700-730, operator|= :628-649, Bit::set :490).
 //
 // Work decomposition
-//   tile      = 1024 consecutive codec blocks (12 288 values) of ONE frame, one 256-thread workgroup.
-//   sub-tile  = 256 blocks; lane `tid` owns block (r*256 + tid) of sub-tile r = 0..3, so every
+//   tile      = 1536 consecutive codec blocks (18 432 values; 768 for 32-bit pixels) of ONE frame, one
+//               256-thread workgroup.
+//   sub-tile  = 256 blocks; lane `tid` owns block (r*256 + tid) of sub-tile r = 0..5, so every
 //               wave-level load covers 1536 contiguous bytes (u16).
 //   The serial bit cursor of the reference (Terse.hpp:504) becomes three prefix sums:
 //     lanes -> wavefront DPP scan, wavefronts/sub-tiles -> LDS, tiles -> decoupled look-back
@@ -14,10 +15,9 @@
 //       frame chain (across the stack) : bytes -> S_f = 1 + bits/8 (Terse.hpp:547) -> frame base
 //   Packing: every lane serialises its block with code specialised on the block's width W (all
 //   shifts static), ORs it into the workgroup's LDS staging image at its scanned bit offset; the
-//   image is flushed to HBM in whole dwords (coalesced), 4 rounds per tile with two staging
-//   buffers (one barrier per round).  A dword shared by two tiles is completed by the later tile
-//   with the earlier tile's tail bits handed over through a third descriptor ("tail" chain), so
-//   the output needs no pre-zeroing and no global atomics.
+//   tile-relative image is flushed to HBM in whole dwords (coalesced) through one funnel shift.  A dword
+//   shared by two tiles is stored by k_stitch from the bits both sides deposit in an exchange word, so
+//   the output needs no pre-zeroing and nothing at a tile's end waits for another tile.
 //
 // Forward progress: tile i only ever waits for tiles < i.  Tiles are taken in blockIdx order,
 // which the hardware dispatches in order; every wait is bounded and raises status[0] =
@@ -30,9 +30,11 @@
 
 namespace trpx {
 
-// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels, 2 (512 blocks) for 32-bit pixels, so that the
-// worst-case LDS image of a whole tile stays ~26 KB (6 workgroups per CU)
-template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
+// sub-tiles per tile: 6 (1536 blocks) for 8/16-bit pixels, 3 (768 blocks) for 32-bit pixels: the worst-case LDS
+// image of a whole tile is then ~39 KB (4 workgroups per CU).  Measured sweep, 2000 x 512^2 u16: 2/3/4/5/6/8
+// sub-tiles -> 0.66/0.59/0.54/0.53/0.48/0.56 ms; 4096^2 i32: 2/3/4 -> 0.28/0.24/0.24 ms (bigger tiles amortise
+// the per-tile scans and look-backs; beyond 6 the occupancy loss wins).
+template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 6 : 3; }
 constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seconds), then give up
 
 // Diagnostics (tools/stamps.py, tools/enc_time.py): only in builds with -DTRPX_DIAGNOSTICS; the product build folds
@@ -273,7 +275,7 @@ struct FusedArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restrict__ pixels, FusedArgs a) {
+__global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restrict__ pixels, FusedArgs a) {
     constexpr int kSub = sub_tiles<T>();
     constexpr int kFusedTileBlocks = kSub * kThreads;
     constexpr int kStage = fused_stage_dwords<T>();
@@ -339,11 +341,12 @@ __global__ __launch_bounds__(kThreads, 6) void k_encode_fused(const T* __restric
     // wave scans, two rounds per 32-bit DPP scan: a wave's 64 blocks are < 2^16 bits (64 * 396 = 25 344)
     static_assert(kWave * max_block_bits<T>() < 65536, "packed scan needs 16-bit wave totals");
 #pragma unroll
-    for (int r = 0; r < kSub; r += 2) {
+    for (int r = 0; r + 1 < kSub; r += 2) {
         const uint32_t two = wave_inclusive_scan(len[r] | (len[r + 1] << 16));
         inc[r] = two & 0xFFFFu;
         inc[r + 1] = two >> 16;
     }
+    if (kSub & 1) inc[kSub - 1] = wave_inclusive_scan(len[kSub - 1]);
 #pragma unroll
     for (int r = 0; r < kSub; ++r) {
         const uint32_t w_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[r]);
