@@ -339,3 +339,39 @@ def test_decode_index_side_channel(gpu, oracle):
     back, st = codec.decode(enc.stack(), enc.frame_offsets, 512 * 512, 2, np.uint16, index=bad)
     torch.cuda.synchronize()
     assert int(st[0].item()) == _lib.ERR_CORRUPT
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_many_small_frames_take_the_per_frame_decoder(gpu, oracle, dtype):
+    """>= 128 frames select k_decode_frames (walker wave + extraction waves per workgroup): differential test
+    against the oracle for every pixel type, mixed widths, partial last blocks, tiny and multi-super-step frames."""
+    rng = np.random.RandomState(23)
+    dt = np.dtype(dtype)
+    bits = dt.itemsize * 8
+    top = bits - 1 if dt.kind == "i" else bits
+    for n, frames in ((1, 130), (11, 130), (388, 150), (12 * 768 + 4, 140), (9216 * 3 + 8, 129)):
+        hi = rng.randint(0, top + 1, size=(frames, (n + 11) // 12))            # a width for every block
+        hi[rng.rand(*hi.shape) < 0.6] = 3 if top >= 3 else 1                    # long runs of one width + outliers
+        mag = np.zeros((frames, n), np.int64)
+        for k in range(12):
+            cols = np.arange(k, n, 12)
+            h = hi[:, : cols.size]
+            mag[:, cols] = (rng.rand(frames, cols.size) * (2.0 ** h)).astype(np.int64)
+        if dt.kind == "i":
+            mag = mag * rng.choice([-1, 1], size=mag.shape)
+            mag = np.clip(mag, np.iinfo(dt).min, np.iinfo(dt).max)
+        px = mag.astype(dt)
+        want, sizes, pb = oracle.encode_stack(px)
+        got, offs, gpb = _host_encode(px)
+        assert got.size == want.size and (got == want).all() and gpb == pb, (dtype, n)
+        assert (np.diff(offs).astype(np.uint64) == sizes).all()
+        assert (_host_decode(want, offs, n, frames, dt) == px).all(), (dtype, n)
+    # a corrupt stack is reported, not decoded
+    from trpx_amd import _lib, TrpxError
+    bad = want.copy()
+    bad[int(offs[5]) : int(offs[5]) + 6] ^= 0xFF
+    try:
+        out = _host_decode(bad, offs, n, frames, dt)
+        assert not (out == px).all()          # (flipping payload bits may still parse: then pixels differ)
+    except TrpxError as e:
+        assert e.code == _lib.ERR_CORRUPT
