@@ -34,7 +34,7 @@ extern "C" {
 typedef enum trpx_status {
     TRPX_OK = 0,
     TRPX_ERR_INVALID_ARG = 1,   /* null/misaligned pointer, zero sizes, unknown dtype        */
-    TRPX_ERR_UNSUPPORTED = 2,   /* e.g. block != 12 on the tuned GPU path, 64-bit pixels      */
+    TRPX_ERR_UNSUPPORTED = 2,   /* block outside 1..4096, decode index with block != 12, ...   */
     TRPX_ERR_CAPACITY = 3,      /* output or workspace too small                              */
     TRPX_ERR_HIP = 4,           /* a HIP runtime call failed (text has the HIP error)         */
     TRPX_ERR_CORRUPT = 5,       /* bitstream runs past its frame / buffer                     */

@@ -41,7 +41,8 @@ def test_pure_arithmetic_entry_points(oracle):
     assert L.trpx_worst_case_bytes(2, 262144, 12) == 524288 + (12 * 21846 + 7) // 8 + 1
     assert L.trpx_encode_workspace_bytes(2, 262144, 2000, 12) > 0
     assert L.trpx_decode_workspace_bytes(2, 262144, 2000, 12) > 2000 * 21846
-    assert L.trpx_encode_workspace_bytes(2, 262144, 2000, 7) == 0      # block != 12: unsupported on the GPU path
+    assert L.trpx_encode_workspace_bytes(2, 262144, 2000, 7) > 0       # any block size 1..4096 (generic kernels)
+    assert L.trpx_encode_workspace_bytes(2, 262144, 2000, 0) == 0 and L.trpx_encode_workspace_bytes(2, 262144, 2000, 5000) == 0
 
 
 def test_header_text_matches_reference_goldens(golden):
@@ -98,9 +99,11 @@ def test_compute_fails_loudly_without_gpu():
 def test_argument_validation_without_gpu():
     from trpx_amd import _lib
     L = _lib.lib()
-    # block != 12 is rejected before anything touches a device
-    rc = L.trpx_encode(2, 16, 100, 1, 7, 16, 0, 16, 16, 16, 1 << 20, None)
+    # an impossible block size is rejected before anything touches a device
+    rc = L.trpx_encode(2, 16, 100, 1, 0, 16, 0, 16, 16, 16, 1 << 20, None)
     assert rc == _lib.ERR_UNSUPPORTED and b"block" in L.trpx_last_error_string()
+    rc = L.trpx_encode_indexed(2, 16, 100, 1, 7, 16, 0, 16, 16, 16, 16, 1 << 20, None)   # the decode index needs block = 12
+    assert rc == _lib.ERR_UNSUPPORTED
     rc = L.trpx_encode(9, 16, 100, 1, 12, 16, 0, 16, 16, 16, 1 << 20, None)
     assert rc == _lib.ERR_INVALID_ARG
     rc = L.trpx_decode(1, 2, 16, 10, None, 100, 1, 12, 16, 16, 16, 1 << 20, None)   # signed stream -> u16

@@ -18,30 +18,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALL_DTYPES = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32]
 
 
-def _host_encode(px2d):
+def _host_encode(px2d, block=12):
     """[frames, n] numpy -> (stream bytes, offsets, prolix_bits) through trpx_encode_host."""
     from trpx_amd import _lib
     from trpx_amd.terse import _code
     L = _lib.lib()
     px2d = np.ascontiguousarray(px2d)
     f, n = px2d.shape
-    cap = f * L.trpx_worst_case_bytes(_code(px2d.dtype), n, 12)
+    cap = f * L.trpx_worst_case_bytes(_code(px2d.dtype), n, block)
     out = np.full(cap, 0xAA, np.uint8)     # poisoned: every output byte must be written
     total, pb = C.c_size_t(0), C.c_uint(0)
     offs = np.zeros(f + 1, np.uint64)
-    _lib.check(L.trpx_encode_host(_code(px2d.dtype), px2d.ctypes.data, n, f, 12, out.ctypes.data, cap,
+    _lib.check(L.trpx_encode_host(_code(px2d.dtype), px2d.ctypes.data, n, f, block, out.ctypes.data, cap,
                                   C.byref(total), offs.ctypes.data, C.byref(pb), -1))
     return out[: total.value].copy(), offs, int(pb.value)
 
 
-def _host_decode(stream, offs, n, frames, dtype):
+def _host_decode(stream, offs, n, frames, dtype, block=12):
     from trpx_amd import _lib
     from trpx_amd.terse import _code
     L = _lib.lib()
     out = np.full((frames, n), 0x55, np.dtype(dtype))
     stream = np.ascontiguousarray(stream)
     _lib.check(L.trpx_decode_host(int(np.dtype(dtype).kind == "i"), _code(dtype), stream.ctypes.data, stream.size,
-                                  offs.ctypes.data if offs is not None else None, n, frames, 12,
+                                  offs.ctypes.data if offs is not None else None, n, frames, block,
                                   out.ctypes.data, -1))
     return out
 
@@ -49,17 +49,15 @@ def _host_decode(stream, offs, n, frames, dtype):
 def test_golden_fixtures_through_c_abi(gpu, golden):
     n_checked = 0
     for c in golden["cases"]:
-        if c["block"] != 12:
-            continue
         px = np.array(c["pixels"], np.dtype(c["dtype"]))
-        s, offs, pb = _host_encode(px.reshape(1, -1))
+        s, offs, pb = _host_encode(px.reshape(1, -1), c["block"])
         assert s.tobytes().hex() == c["stream"], c["name"]
         assert pb == c["prolix_bits"], c["name"]
         assert int(offs[1]) == len(c["stream"]) // 2
         want = np.frombuffer(bytes.fromhex(c["stream"]), np.uint8)
-        assert (_host_decode(want, None, px.size, 1, px.dtype)[0] == px).all(), c["name"]
+        assert (_host_decode(want, None, px.size, 1, px.dtype, c["block"])[0] == px).all(), c["name"]
         n_checked += 1
-    assert n_checked >= 30
+    assert n_checked >= 36 and any(c["block"] != 12 for c in golden["cases"])
 
 
 def test_golden_stack_layout(gpu, golden):
@@ -375,3 +373,40 @@ def test_many_small_frames_take_the_per_frame_decoder(gpu, oracle, dtype):
         assert not (out == px).all()          # (flipping payload bits may still parse: then pixels differ)
     except TrpxError as e:
         assert e.code == _lib.ERR_CORRUPT
+
+
+@pytest.mark.parametrize("block", [1, 3, 7, 16, 100, 4096])
+def test_any_block_size_generic_kernels(gpu, oracle, block):
+    """The `block` argument of Terse(Iterator, size, block) (Terse.hpp:263-270): every size other than the tuned
+    default 12 goes through the generic kernels; differential test against the oracle."""
+    rng = np.random.RandomState(block)
+    for dt in (np.uint8, np.int16, np.uint16, np.int32):
+        info = np.iinfo(dt)
+        for n, frames in ((1, 2), (block, 1), (block * 3 + 1, 3), (5000, 2), (70001, 2)):
+            hi = rng.randint(0, info.bits - (1 if dt().dtype.kind == "i" else 0) + 1)
+            mag = (rng.rand(frames, n) * (2.0 ** hi)).astype(np.int64)
+            mag[:, : n // 3] = 0
+            if np.dtype(dt).kind == "i":
+                mag = np.clip(mag * rng.choice([-1, 1], size=mag.shape), info.min, info.max)
+            px = mag.astype(dt)
+            parts = [oracle.encode(px[f], block) for f in range(frames)]
+            want = np.concatenate([p[0] for p in parts])
+            got, offs, gpb = _host_encode(px, block)
+            assert got.size == want.size and (got == want).all(), (block, dt, n)
+            assert gpb == max(p[1] for p in parts)
+            assert [int(x) for x in np.diff(offs)] == [p[0].size for p in parts]
+            assert (_host_decode(want, offs, n, frames, dt, block) == px).all(), (block, dt, n)
+            assert (_host_decode(want, None, n, frames, dt, block) == px).all(), (block, dt, n)
+
+
+def test_terse_class_with_block_argument(gpu, oracle, golden):
+    from trpx_amd import Terse
+    c = [c for c in golden["cases"] if c["name"] == "block16_u16"][0]
+    px = np.array(c["pixels"], np.uint16)
+    t = Terse(px, block=16)
+    buf = io.BytesIO()
+    t.write(buf)
+    assert buf.getvalue() == c["header"].encode() + bytes.fromhex(c["stream"])   # the reference's own file, byte for byte
+    buf.seek(0)
+    r = Terse.read(buf)
+    assert (r.prolix(np.empty(px.size, np.uint16)) == px).all()

@@ -36,13 +36,16 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(TRPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+constexpr unsigned kMaxBlock = 4096;   // generic kernels: tile bit counts stay well inside 32 bits
+
 bool geom_of(size_t n_values, unsigned block, trpx::FrameGeom* g) {
-    if (n_values == 0 || block != (unsigned)trpx::kBlock) return false;
-    const uint64_t nb = (n_values + trpx::kBlock - 1) / trpx::kBlock;
+    if (n_values == 0 || block == 0 || block > kMaxBlock) return false;
+    const uint64_t nb = (n_values + block - 1) / block;
     if (nb > 0xFFFFFFFFull) return false;
     g->n_values = n_values;
     g->n_blocks = (uint32_t)nb;
     g->n_tiles = (uint32_t)((nb + trpx::kTileBlocks - 1) / trpx::kTileBlocks);
+    g->block = block;
     return true;
 }
 
@@ -147,8 +150,8 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
                         void* workspace, size_t workspace_bytes, void* stream) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: unknown dtype %d", dtype);
-    if (block != (unsigned)trpx::kBlock)
-        return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode: block=%u (the GPU path implements the format's default block=12, Terse.hpp:264)", block);
+    if (block == 0 || block > kMaxBlock)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode: block=%u (supported: 1..%u; 12 is the tuned default, Terse.hpp:264)", block, kMaxBlock);
     if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
     if (!pixels || !frame_offsets || !status || !workspace || (!out && out_capacity))
@@ -176,6 +179,11 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     const IdxLayout il = idx_layout(g, n_frames);
     a.idx_group_off = index ? reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off) : nullptr;
     a.idx_widths = index ? reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths) : nullptr;
+    if (block != (unsigned)trpx::kBlock) {                 // any other block size: generic (correct-first) kernels
+        if (index) return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode_indexed: the decode index needs block=12");
+        HIP_TRY(trpx::launch_encode_generic(dtype, a, static_cast<hipStream_t>(stream)));
+        return TRPX_OK;
+    }
     const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0;
     if (g_encode_path == 0 && vec_ok)
         HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
@@ -192,8 +200,8 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
                 uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(out_dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: unknown dtype %d", out_dtype);
-    if (block != (unsigned)trpx::kBlock)
-        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: block=%u (GPU path implements block=12)", block);
+    if (block == 0 || block > kMaxBlock)
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: block=%u (supported: 1..%u)", block, kMaxBlock);
     if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: stream signed=%d into dtype %d: only same-signedness decode "
                     "is defined by the reference (Terse.hpp:356-357)", stream_signed, out_dtype);
@@ -224,7 +232,8 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     static const bool basic = strcmp(dpath, "basic") == 0;
     static const bool force_tiles = strcmp(dpath, "tiles") == 0, force_frames = strcmp(dpath, "frames") == 0;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
-    const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0;
+    const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0 &&
+                         block == (unsigned)trpx::kBlock;
     // many small frames: one workgroup per frame, the walk and the extraction overlap inside it;
     // few large frames: the tiled kernels (the walk is then the whole critical path either way)
     if (fast_ok && !force_tiles && (force_frames || n_frames >= 128))
@@ -240,8 +249,9 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
                             size_t n_values, size_t n_frames, unsigned block, void* index, uint32_t* status,
                             bool clear_status, void* stream) {
     trpx::FrameGeom g;
+    if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: the decode index needs block=12");
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !n_frames || !terse_bytes)
-        return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG, "trpx_build_index: bad dtype/sizes/block");
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: bad dtype/sizes");
     if (!terse || !frame_offsets || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: null pointer");
     if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: misaligned pointer");

@@ -20,6 +20,7 @@ struct FrameGeom {
     uint64_t n_values;   // per frame
     uint32_t n_blocks;   // ceil(n_values / 12)
     uint32_t n_tiles;    // ceil(n_blocks / 256)
+    uint32_t block;      // values per codec block: 12 on every tuned path; the generic kernels take any value
 };
 
 template <typename T> struct PixelTraits;

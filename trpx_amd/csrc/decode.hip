@@ -36,13 +36,13 @@ __device__ uint64_t walk_frame(const uint32_t* __restrict__ s32, uint64_t n_dw, 
                                uint64_t limit_bits, const FrameGeom g, uint32_t max_w,
                                uint8_t* __restrict__ widths_f, uint64_t* __restrict__ tile_off_f) {
     const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);
+    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * g.block);
     uint32_t b = 0, w_prev = 0;
     uint64_t pos = 0;
     uint64_t final_pos = 0;
     bool bad = false;
     while (b < g.n_blocks) {
-        const uint32_t stride = 1u + kBlock * w_prev;
+        const uint32_t stride = 1u + g.block * w_prev;
         const uint32_t cb = b + lane;
         const uint64_t cpos = pos + (uint64_t)lane * stride;
         const bool in_range = cb < g.n_blocks;
@@ -66,7 +66,7 @@ __device__ uint64_t walk_frame(const uint32_t* __restrict__ s32, uint64_t n_dw, 
                 if (w == 10u) { w += (bits >> 6) & 63u; hl = 12; }       // :368
             }
             if (w > max_w) { lane_bad = true; w = 0; }
-            const uint32_t nbv = cb + 1 == g.n_blocks ? nb_last : (uint32_t)kBlock;
+            const uint32_t nbv = cb + 1 == g.n_blocks ? nb_last : g.block;
             npos = cpos + hl + (uint64_t)nbv * w;
             nw = w;
             widths_f[cb] = (uint8_t)w;
@@ -228,6 +228,49 @@ __global__ __launch_bounds__(kThreads) void k_unpack(const uint8_t* __restrict__
     }
 }
 
+// Any block size (see encode.hip's generic kernels): one lane per block, values read / written one by one.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_unpack_g(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                       const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                       const uint8_t* __restrict__ widths,
+                                                       const uint64_t* __restrict__ tile_off,
+                                                       T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_tot[4];
+    if (status[0] != 0) return;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t frame = (uint32_t)(tile / g.n_tiles), t = (uint32_t)(tile % g.n_tiles);
+    const uint32_t b = t * kTileBlocks + threadIdx.x;
+    const bool valid = b < g.n_blocks;
+    const uint8_t* wf = widths + (uint64_t)frame * g.n_blocks;
+    uint32_t w = 0, w_prev = 0, nb = 0;
+    if (valid) {
+        w = wf[b];
+        w_prev = b ? wf[b - 1] : 0u;
+        const uint64_t first = (uint64_t)b * g.block;
+        nb = (uint32_t)(first + g.block <= g.n_values ? g.block : g.n_values - first);
+    }
+    const uint32_t hl = header_len(w, w_prev);
+    const uint32_t len = valid ? hl + nb * w : 0u;
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(len, s_tot, &total);
+    if (!valid) return;
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    const uint64_t pos = tile_off[tile] + excl + hl;
+    T* dst = pixels_out + (uint64_t)frame * g.n_values + (uint64_t)b * g.block;
+    if (w == 0) { for (uint32_t k = 0; k < nb; ++k) dst[k] = (T)0; return; }
+    if (pos + (uint64_t)nb * w > 8 * (fe - fo) || w > (uint32_t)PixelTraits<T>::bits) { atomicMax(&status[0], 5u); return; }
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(terse);
+    const uint64_t n_dw = (terse_bytes + 3) / 4;
+    const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+    uint64_t abit = 8 * fo + pos;
+    for (uint32_t k = 0; k < nb; ++k, abit += w) {
+        const uint64_t two = (uint64_t)ld_stream_dw(s32, abit >> 5, n_dw) | ((uint64_t)ld_stream_dw(s32, (abit >> 5) + 1, n_dw) << 32);
+        uint32_t u = (uint32_t)(two >> (abit & 31)) & mask;
+        if (PixelTraits<T>::is_signed) u = (uint32_t)((int32_t)(u << (32u - w)) >> (32u - w));
+        dst[k] = (T)u;
+    }
+}
+
 template <typename T>
 static hipError_t launch_decode_t(const DecodeArgs& a, bool have_offsets, hipStream_t st) {
     const FrameGeom g = a.geom;
@@ -249,7 +292,10 @@ static hipError_t launch_decode_t(const DecodeArgs& a, bool have_offsets, hipStr
     }
     prof.mark(st);
     T* out = static_cast<T*>(a.pixels_out);
-    if (vec) hipLaunchKernelGGL((k_unpack<T, true>), dim3((uint32_t)n_tiles_total), dim3(kThreads), 0, st, a.terse,
+    if (g.block != (uint32_t)kBlock)
+        hipLaunchKernelGGL((k_unpack_g<T>), dim3((uint32_t)n_tiles_total), dim3(kThreads), 0, st, a.terse,
+                           (uint64_t)a.terse_bytes, offs, g, a.widths, a.tile_off, out, a.status);
+    else if (vec) hipLaunchKernelGGL((k_unpack<T, true>), dim3((uint32_t)n_tiles_total), dim3(kThreads), 0, st, a.terse,
                                 (uint64_t)a.terse_bytes, offs, g, a.widths, a.tile_off, out, a.status);
     else     hipLaunchKernelGGL((k_unpack<T, false>), dim3((uint32_t)n_tiles_total), dim3(kThreads), 0, st, a.terse,
                                 (uint64_t)a.terse_bytes, offs, g, a.widths, a.tile_off, out, a.status);

@@ -354,6 +354,134 @@ static hipError_t launch_encode_t(const EncodeArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any block size (the `block` argument of Terse(Iterator, size, block), Terse.hpp:263-270, and the header's
+// `block` attribute).  Correct-first kernels: one lane per block looping over its values, output pre-zeroed
+// and written with 32-bit atomic ORs.  block == 12 never comes here.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ uint32_t block_width_g(const T* __restrict__ frame, uint64_t first, uint32_t nb) {
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < nb; ++k) m |= magnitude<T>(frame[first + k]);      // OR-scan (Terse.hpp:508-514)
+    return width_from_or<T>(m);
+}
+
+// width of block b and of the block before it (0 at the start of a frame); one __syncthreads()
+template <typename T>
+__device__ __forceinline__ void widths_g(const T* __restrict__ frame, const FrameGeom& g, uint32_t t, uint32_t* s_w,
+                                         uint32_t& nb, uint32_t& w, uint32_t& w_prev, bool& valid) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = t * kTileBlocks + tid;
+    valid = b < g.n_blocks;
+    nb = 0;
+    w = 0;
+    if (valid) {
+        const uint64_t first = (uint64_t)b * g.block;
+        nb = (uint32_t)(first + g.block <= g.n_values ? g.block : g.n_values - first);
+        w = block_width_g<T>(frame, first, nb);
+    }
+    s_w[tid + 1] = w;
+    if (tid == 0) s_w[0] = t > 0 ? block_width_g<T>(frame, (uint64_t)(b - 1) * g.block, g.block) : 0u;
+    __syncthreads();
+    w_prev = s_w[tid];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_tile_bits_g(const T* __restrict__ pixels, FrameGeom g,
+                                                          uint32_t* __restrict__ tile_bits, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_w[kThreads + 1];
+    __shared__ uint32_t s_tot[4];
+    __shared__ uint32_t s_max[4];
+    const uint64_t tile = blockIdx.x;
+    const uint32_t frame = (uint32_t)(tile / g.n_tiles), t = (uint32_t)(tile % g.n_tiles);
+    uint32_t nb, w, w_prev;
+    bool valid;
+    widths_g<T>(pixels + (uint64_t)frame * g.n_values, g, t, s_w, nb, w, w_prev, valid);
+    const uint32_t len = valid ? header_len(w, w_prev) + nb * w : 0u;
+    uint32_t total;
+    block_exclusive_scan(len, s_tot, &total);
+    const uint32_t mx = wave_max(w);
+    if (lane_id() == 0) s_max[wave_id()] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_bits[tile] = total;
+        const uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (m > __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[1], m);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_zero_out_g(const uint64_t* __restrict__ frame_offsets, uint32_t n_frames,
+                                                         uint32_t* __restrict__ out32, const uint32_t* __restrict__ status) {
+    if (status[0] != 0) return;
+    const uint64_t n_dw = (frame_offsets[n_frames] + 3) / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n_dw; i += (uint64_t)gridDim.x * kThreads) out32[i] = 0u;
+}
+
+__device__ __forceinline__ void or_bits_g(uint32_t* __restrict__ out32, uint64_t abit, uint32_t val, uint32_t len) {
+    if (!len) return;
+    const uint64_t x = (uint64_t)val << (abit & 31);
+    if ((uint32_t)x) atomicOr(&out32[abit >> 5], (uint32_t)x);
+    if ((uint32_t)(x >> 32)) atomicOr(&out32[(abit >> 5) + 1], (uint32_t)(x >> 32));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_pack_g(const T* __restrict__ pixels, FrameGeom g,
+                                                     const uint64_t* __restrict__ tile_off,
+                                                     const uint64_t* __restrict__ frame_offsets,
+                                                     uint32_t* __restrict__ out32, const uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_w[kThreads + 1];
+    __shared__ uint32_t s_tot[4];
+    if (status[0] != 0) return;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t frame = (uint32_t)(tile / g.n_tiles), t = (uint32_t)(tile % g.n_tiles);
+    const T* fp = pixels + (uint64_t)frame * g.n_values;
+    uint32_t nb, w, w_prev;
+    bool valid;
+    widths_g<T>(fp, g, t, s_w, nb, w, w_prev, valid);
+    const uint32_t hl = header_len(w, w_prev);
+    const uint32_t len = valid ? hl + nb * w : 0u;
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(len, s_tot, &total);
+    if (!valid) return;
+    uint64_t abit = 8 * frame_offsets[frame] + tile_off[tile] + excl;
+    or_bits_g(out32, abit, header_val(w, w_prev), hl);
+    abit += hl;
+    if (w) {
+        const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+        const uint64_t first = (uint64_t)(t * kTileBlocks + threadIdx.x) * g.block;
+        for (uint32_t k = 0; k < nb; ++k, abit += w) or_bits_g(out32, abit, (uint32_t)fp[first + k] & mask, w);   // Bit_pointer.hpp:707-711
+    }
+}
+
+template <typename T>
+static hipError_t launch_encode_generic_t(const EncodeArgs& a, hipStream_t st) {
+    const FrameGeom g = a.geom;
+    const uint64_t n_tiles_total = (uint64_t)a.n_frames * g.n_tiles;
+    const T* px = static_cast<const T*>(a.pixels);
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(a.out);
+    const dim3 grid((uint32_t)n_tiles_total), blk(kThreads);
+    zero_status(a.status, st);
+    hipLaunchKernelGGL((k_tile_bits_g<T>), grid, blk, 0, st, px, g, a.tile_bits, a.status);
+    hipLaunchKernelGGL(k_frame_scan, dim3(a.n_frames), blk, 0, st, a.tile_bits, g, a.tile_off, a.frame_size);
+    hipLaunchKernelGGL(k_stack_scan, dim3(1), blk, 0, st, a.frame_size, a.n_frames, (uint64_t)a.out_capacity,
+                       a.frame_offsets, a.status);
+    hipLaunchKernelGGL(k_zero_out_g, dim3(1024), blk, 0, st, a.frame_offsets, a.n_frames, out32, a.status);
+    hipLaunchKernelGGL((k_pack_g<T>), grid, blk, 0, st, px, g, a.tile_off, a.frame_offsets, out32, a.status);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_generic(int dtype, const EncodeArgs& a, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_encode_generic_t<uint8_t>(a, st);
+    case 1: return launch_encode_generic_t<int8_t>(a, st);
+    case 2: return launch_encode_generic_t<uint16_t>(a, st);
+    case 3: return launch_encode_generic_t<int16_t>(a, st);
+    case 4: return launch_encode_generic_t<uint32_t>(a, st);
+    case 5: return launch_encode_generic_t<int32_t>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st) {
     switch (dtype) {
     case 0: return launch_encode_t<uint8_t>(a, st);

@@ -39,6 +39,8 @@ struct DecodeArgs {
 };
 
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
+// any block size (encode.hip, correct-first kernels): geom.block != 12
+hipError_t launch_encode_generic(int dtype, const EncodeArgs& a, hipStream_t st);
 // single-pass encoder (encode_fused.hip); `ws` = fused_workspace_bytes() of descriptor words
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStream_t st);
