@@ -580,7 +580,6 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     // every polled / OR-ed word and the status block, cleared on every call (see k_zero_words)
     hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
                        (uint64_t)(3 * tiles + e.n_frames), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
-    hipError_t err = hipSuccess;
     prof.mark(st);
     hipLaunchKernelGGL((k_encode_fused<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, st,
                        static_cast<const T*>(e.pixels), a);
