@@ -82,13 +82,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// Maximum over the 64 lanes (same DPP ladder as the scan; every lane gets the result).
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    auto step = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
