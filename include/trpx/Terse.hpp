@@ -35,6 +35,12 @@ template <typename T> constexpr int dtype_of() {
     static_assert(std::is_integral_v<T> && sizeof(T) <= 4, "trpx::Terse: pixel type must be an integer of <= 32 bits");
     return (sizeof(T) == 1 ? TRPX_U8 : sizeof(T) == 2 ? TRPX_U16 : TRPX_U32) + (std::is_signed_v<T> ? 1 : 0);
 }
+// output types of prolix(): the pixel types plus float / double (Terse.hpp:379-383)
+template <typename T> constexpr int out_dtype_of() {
+    if constexpr (std::is_same_v<T, float>) return TRPX_F32;
+    else if constexpr (std::is_same_v<T, double>) return TRPX_F64;
+    else return dtype_of<T>();
+}
 inline void check(int rc, const char* what) {
     if (rc == TRPX_OK) return;
     std::string msg = std::string(what) + ": " + trpx_last_error_string();
@@ -104,20 +110,22 @@ public:
         prolix(data.begin(), frame);
     }
 
-    /// Unpacks a frame to `begin` (Terse.hpp:352-389). Same-type decode.
+    /// Unpacks a frame to `begin` (Terse.hpp:352-389).  The output type is free: narrower integers clamp
+    /// (Bit_pointer.hpp:747-763), float / double are exact (:379-383), unsigned data into a signed type keeps
+    /// the value (the reference sign-extends wrongly there).
     template <typename Iterator>
         requires requires(Iterator& i) { *i; }
     void prolix(Iterator begin, std::size_t frame = 0) {
         using V = typename std::iterator_traits<Iterator>::value_type;
         if (frame >= number_of_frames()) throw std::invalid_argument("prolix: frame index out of range");
-        if (d_signed && !std::is_signed_v<V>)
+        if (d_signed && std::is_unsigned_v<V>)
             throw std::invalid_argument("signed data cannot be decompressed into unsigned data");
         const std::size_t start = std::accumulate(d_frame_sizes.begin(), d_frame_sizes.begin() + frame, std::size_t(0));
         std::vector<V> tmp;
         V* dst;
         if constexpr (std::is_pointer_v<Iterator>) dst = begin;
         else { tmp.resize(d_size); dst = tmp.data(); }
-        detail::check(trpx_decode_host(d_signed, detail::dtype_of<V>(), d_terse_data.data() + start, d_frame_sizes[frame],
+        detail::check(trpx_decode_host(d_signed, detail::out_dtype_of<V>(), d_terse_data.data() + start, d_frame_sizes[frame],
                                        nullptr, d_size, 1, d_block, dst, -1), "Terse::prolix");
         if constexpr (!std::is_pointer_v<Iterator>) std::copy(tmp.begin(), tmp.end(), begin);
     }

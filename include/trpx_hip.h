@@ -45,7 +45,8 @@ typedef enum trpx_status {
 
 /* Pixel types = the reference CLI's dispatch set (src/terse.cpp:113-118). Odd = signed. */
 typedef enum trpx_dtype {
-    TRPX_U8 = 0, TRPX_I8 = 1, TRPX_U16 = 2, TRPX_I16 = 3, TRPX_U32 = 4, TRPX_I32 = 5
+    TRPX_U8 = 0, TRPX_I8 = 1, TRPX_U16 = 2, TRPX_I16 = 3, TRPX_U32 = 4, TRPX_I32 = 5,
+    TRPX_F32 = 6, TRPX_F64 = 7      /* output types of trpx_decode_convert / trpx_decode_host only */
 } trpx_dtype;
 
 /* Device status block written by the kernels (u32 words); zeroed by each call's first node. */
@@ -108,6 +109,21 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
                 const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block,
                 void* pixels_out, uint32_t* status, void* workspace, size_t workspace_bytes,
                 void* stream);
+
+/*
+ * Converting decode: the output type is free and the stream's signedness is given separately.  Replaces the
+ * cross-type branches of jpa::Terse::prolix / Bit_range::get_range: narrower integral output clamps to
+ * numeric_limits (Bit_pointer.hpp:747-763), float / double output is exact (Terse.hpp:379-383,
+ * Bit_range::next :580-587), wider integral output keeps the value -- also for an unsigned stream into a
+ * signed type, where the reference sign-extends wrongly.  out_dtype: TRPX_U8 .. TRPX_F64;
+ * workspace: trpx_decode_workspace_bytes().  Correct-first kernels (one lane per block).
+ * trpx_decode_host picks this path by itself when out_dtype does not match the stream's signedness or is a
+ * floating-point type.
+ */
+int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                        const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block,
+                        void* pixels_out, uint32_t* status, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /*
  * Decode index.  The .trpx stream stores no index, so a plain trpx_decode first walks

@@ -34,13 +34,14 @@ def _host_encode(px2d, block=12):
     return out[: total.value].copy(), offs, int(pb.value)
 
 
-def _host_decode(stream, offs, n, frames, dtype, block=12):
+def _host_decode(stream, offs, n, frames, dtype, block=12, stream_signed=None):
     from trpx_amd import _lib
     from trpx_amd.terse import _code
     L = _lib.lib()
     out = np.full((frames, n), 0x55, np.dtype(dtype))
     stream = np.ascontiguousarray(stream)
-    _lib.check(L.trpx_decode_host(int(np.dtype(dtype).kind == "i"), _code(dtype), stream.ctypes.data, stream.size,
+    _lib.check(L.trpx_decode_host(int(np.dtype(dtype).kind == "i") if stream_signed is None else int(stream_signed),
+                                  _code(dtype, True), stream.ctypes.data, stream.size,
                                   offs.ctypes.data if offs is not None else None, n, frames, block,
                                   out.ctypes.data, -1))
     return out
@@ -410,3 +411,39 @@ def test_terse_class_with_block_argument(gpu, oracle, golden):
     buf.seek(0)
     r = Terse.read(buf)
     assert (r.prolix(np.empty(px.size, np.uint16)) == px).all()
+
+
+def test_converting_decode_cross_type_and_float(gpu, oracle):
+    """Rows a9 (clamping into narrower types, Bit_pointer.hpp:747-763) and a10 (float / double output,
+    Terse.hpp:379-383): trpx_decode_convert against the oracle's value semantics."""
+    rng = np.random.RandomState(41)
+    for src in (np.uint16, np.int16, np.int32, np.uint32):
+        s_signed = np.dtype(src).kind == "i"
+        info = np.iinfo(src)
+        n, frames = 5003, 3
+        mag = (rng.rand(frames, n) * (2.0 ** rng.randint(1, info.bits - (1 if s_signed else 0), size=(frames, 1)))).astype(np.int64)
+        mag[:, ::7] = 0
+        if s_signed:
+            mag = np.clip(mag * rng.choice([-1, 1], size=mag.shape), info.min, info.max)
+        px = mag.astype(src)
+        stream, sizes, pb = oracle.encode_stack(px)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        for dst in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64):
+            if s_signed and np.dtype(dst).kind == "u":
+                continue                                   # the reference asserts against it (Terse.hpp:356-357)
+            got = _host_decode(stream, offs, n, frames, dst, stream_signed=s_signed)
+            if np.dtype(dst).kind == "f":
+                want = px.astype(dst)                      # exact: |v| < 2^32 fits double; float32 rounds like a cast
+            else:
+                di = np.iinfo(dst)
+                want = np.clip(px.astype(np.int64), di.min, di.max).astype(dst)
+                chk = np.stack([oracle.decode(stream[int(offs[f]):int(offs[f + 1])], n, dst, stream_signed=s_signed) for f in range(frames)])
+                assert (chk == want).all()
+            assert (got == want).all(), (src, dst)
+    # the class surface: decode a u16 object into int32 / float64 containers
+    from trpx_amd import Terse
+    px = rng.randint(0, 60000, size=4000).astype(np.uint16)
+    t = Terse(px)
+    assert (t.prolix(np.empty(4000, np.int32)) == px.astype(np.int32)).all()
+    assert (t.prolix(np.empty(4000, np.float64)) == px.astype(np.float64)).all()
+    assert (t.prolix(np.empty(4000, np.uint8)) == np.minimum(px, 255).astype(np.uint8)).all()

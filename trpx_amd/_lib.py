@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRPX_LIB") or os.path.join(_HERE, "libtrpx_hip.so")   # TRPX_LIB: kernel experiments only
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_CORRUPT, ERR_NO_DEVICE, ERR_TIMEOUT = range(8)
-U8, I8, U16, I16, U32, I32 = range(6)
+U8, I8, U16, I16, U32, I32, F32, F64 = range(8)
 STATUS_WORDS = 8
 
 
@@ -46,6 +46,7 @@ SYMBOLS = {
     "trpx_encode_indexed": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
     "trpx_build_index": (_I, [_I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P]),
     "trpx_decode_indexed": (_I, [_I, _I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _P, _P, _P]),
+    "trpx_decode_convert": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P, _SZ, _P]),
     "trpx_encode_host": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, C.POINTER(_SZ), _P, C.POINTER(_U), _I]),
     "trpx_decode_host": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _I]),
     "trpx_frame_offsets_host": (_I, [_P, _SZ, _SZ, _SZ, _U, _U, _P, _I]),

@@ -306,6 +306,37 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     return TRPX_OK;
 }
 
+int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
+                        const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
+                        uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    trpx::FrameGeom g;
+    const size_t es = out_dtype == TRPX_F32 ? 4 : out_dtype == TRPX_F64 ? 8 : trpx_dtype_size(out_dtype);
+    if (!es) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: unknown dtype %d", out_dtype);
+    if (block == 0 || block > kMaxBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_convert: block=%u", block);
+    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: bad sizes");
+    if (!terse || !pixels_out || !status || !workspace) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: null pointer");
+    if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8 ||
+        (uintptr_t)pixels_out % es)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: misaligned pointer");
+    const DecWs w = dec_ws(g, n_frames);
+    if (workspace_bytes < w.total) return fail(TRPX_ERR_CAPACITY, "trpx_decode_convert: workspace %zu < %zu", workspace_bytes, w.total);
+    trpx::DecodeArgs a{};
+    a.terse = terse;
+    a.terse_bytes = terse_bytes;
+    a.frame_offsets = frame_offsets;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.pixels_out = pixels_out;
+    a.status = status;
+    char* ws = static_cast<char*>(workspace);
+    a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
+    a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
+    a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
+    HIP_TRY(trpx::launch_decode_convert(out_dtype, a, stream_signed != 0, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
 int trpx_set_encode_path(int path) {
     if (path != 0 && path != 1) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_encode_path: 0 = auto, 1 = two-pass");
     g_encode_path = path;
@@ -390,10 +421,10 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
                      void* pixels_out, int device) {
     if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_decode_host: no HIP device");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
-    const size_t es = trpx_dtype_size(out_dtype);
+    const size_t es = out_dtype == TRPX_F32 ? 4 : out_dtype == TRPX_F64 ? 8 : trpx_dtype_size(out_dtype);
     if (!es || !terse || !pixels_out || !terse_bytes) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_host: bad argument");
     const size_t out_bytes = n_values * n_frames * es;
-    const size_t ws_bytes = trpx_decode_workspace_bytes(out_dtype, n_values, n_frames, block);
+    const size_t ws_bytes = trpx_decode_workspace_bytes(TRPX_U8, n_values, n_frames, block);
     if (!ws_bytes) return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
                                "trpx_decode_host: unsupported sizes/block (block=%u)", block);
     DevBuf d_in, d_out, d_off, d_st, d_ws;
@@ -407,13 +438,25 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
         HIP_TRY(d_off.alloc(8 * (n_frames + 1)));
         HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
     }
-    int rc = trpx_decode(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes,
-                         frame_offsets ? static_cast<const uint64_t*>(d_off.p) : nullptr, n_values, n_frames, block,
-                         d_out.p, static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    // Same signedness: the tuned decoders.  They report CORRUPT for a block wider than the output type, which is also
+    // what a legitimately wider stream looks like (e.g. u16 data into a u8 container, Bit_pointer.hpp:747-763): those
+    // -- and every cross-kind / float / double request -- take the converting decoder, whose verdict is final.
+    const uint64_t* offs_dev = frame_offsets ? static_cast<const uint64_t*>(d_off.p) : nullptr;
+    bool convert = !(out_dtype <= TRPX_I32 && (stream_signed != 0) == (trpx_dtype_is_signed(out_dtype) != 0));
     uint32_t st[TRPX_STATUS_WORDS];
-    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    for (;;) {
+        const int rc = convert ? trpx_decode_convert(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes,
+                                                     offs_dev, n_values, n_frames, block, d_out.p,
+                                                     static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr)
+                               : trpx_decode(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, offs_dev,
+                                             n_values, n_frames, block, d_out.p, static_cast<uint32_t*>(d_st.p), d_ws.p,
+                                             ws_bytes, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+        if (st[0] == TRPX_ERR_CORRUPT && !convert && es < 4) { convert = true; continue; }
+        break;
+    }
     if (st[0]) return fail((int)st[0], "trpx_decode_host: corrupt or truncated stream (device status %u)", st[0]);
     HIP_TRY(hipMemcpy(pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
     return TRPX_OK;

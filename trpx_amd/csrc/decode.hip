@@ -14,6 +14,7 @@
 #include "codec_common.hpp"
 #include "encode_kernels.hpp"
 #include "profile.hpp"
+#include <type_traits>
 
 namespace trpx {
 
@@ -319,6 +320,99 @@ hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipS
     case 3: return launch_decode_t<int16_t>(a, have_offsets, st);
     case 4: return launch_decode_t<uint32_t>(a, have_offsets, st);
     case 5: return launch_decode_t<int32_t>(a, have_offsets, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Converting decode: any output type, the stream's signedness given separately.  Values are zero- (unsigned
+// stream) or sign-extended (signed stream) from the block width, then stored with clamping into a narrower
+// integral type (Bit_pointer.hpp:747-763) or exactly into float / double (Terse.hpp:379-383, Bit_range::next
+// :580-587).  Correct value semantics also for an unsigned stream into a signed type (reference defect D4).
+// ---------------------------------------------------------------------------------------------
+template <typename OutT>
+__device__ __forceinline__ OutT convert_clamped(int64_t v) {
+    if constexpr (std::is_floating_point<OutT>::value) return (OutT)v;
+    else {
+        constexpr int64_t lo = std::is_signed<OutT>::value ? -(int64_t(1) << (8 * sizeof(OutT) - 1)) : 0;
+        constexpr int64_t hi = std::is_signed<OutT>::value ? (int64_t(1) << (8 * sizeof(OutT) - 1)) - 1
+                                                           : (int64_t(1) << (8 * sizeof(OutT))) - 1;
+        return (OutT)(v < lo ? lo : (v > hi ? hi : v));
+    }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(kThreads) void k_unpack_conv(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                          const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                          int stream_signed, const uint8_t* __restrict__ widths,
+                                                          const uint64_t* __restrict__ tile_off,
+                                                          OutT* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_tot[4];
+    if (status[0] != 0) return;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t frame = (uint32_t)(tile / g.n_tiles), t = (uint32_t)(tile % g.n_tiles);
+    const uint32_t b = t * kTileBlocks + threadIdx.x;
+    const bool valid = b < g.n_blocks;
+    const uint8_t* wf = widths + (uint64_t)frame * g.n_blocks;
+    uint32_t w = 0, w_prev = 0, nb = 0;
+    if (valid) {
+        w = wf[b];
+        w_prev = b ? wf[b - 1] : 0u;
+        const uint64_t first = (uint64_t)b * g.block;
+        nb = (uint32_t)(first + g.block <= g.n_values ? g.block : g.n_values - first);
+    }
+    const uint32_t hl = header_len(w, w_prev);
+    const uint32_t len = valid ? hl + nb * w : 0u;
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(len, s_tot, &total);
+    if (!valid) return;
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    const uint64_t pos = tile_off[tile] + excl + hl;
+    OutT* dst = pixels_out + (uint64_t)frame * g.n_values + (uint64_t)b * g.block;
+    if (w == 0) { for (uint32_t k = 0; k < nb; ++k) dst[k] = (OutT)0; return; }
+    if (pos + (uint64_t)nb * w > 8 * (fe - fo) || w > 32u) { atomicMax(&status[0], 5u); return; }
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(terse);
+    const uint64_t n_dw = (terse_bytes + 3) / 4;
+    const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+    uint64_t abit = 8 * fo + pos;
+    for (uint32_t k = 0; k < nb; ++k, abit += w) {
+        const uint64_t two = (uint64_t)ld_stream_dw(s32, abit >> 5, n_dw) | ((uint64_t)ld_stream_dw(s32, (abit >> 5) + 1, n_dw) << 32);
+        const uint32_t u = (uint32_t)(two >> (abit & 31)) & mask;
+        const int64_t v = stream_signed ? (int64_t)((int32_t)(u << (32u - w)) >> (32u - w)) : (int64_t)u;
+        dst[k] = convert_clamped<OutT>(v);
+    }
+}
+
+template <typename OutT>
+static hipError_t launch_decode_convert_t(const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st) {
+    const FrameGeom g = a.geom;
+    zero_status(a.status, st);
+    const uint64_t* offs = a.frame_offsets;
+    if (have_offsets) {
+        hipLaunchKernelGGL(k_walk, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, offs, g, 32u,
+                           a.widths, a.tile_off, a.status);
+    } else {
+        hipLaunchKernelGGL(k_walk_serial, dim3(1), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.n_frames, g, 32u,
+                           a.widths, a.tile_off, a.walk_offsets, a.status);
+        offs = a.walk_offsets;
+    }
+    hipLaunchKernelGGL((k_unpack_conv<OutT>), dim3((uint32_t)((uint64_t)a.n_frames * g.n_tiles)), dim3(kThreads), 0, st,
+                       a.terse, (uint64_t)a.terse_bytes, offs, g, stream_signed, a.widths, a.tile_off,
+                       static_cast<OutT*>(a.pixels_out), a.status);
+    return hipGetLastError();
+}
+
+// dtype: 0..5 = the integral pixel types, 6 = float, 7 = double
+hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_decode_convert_t<uint8_t>(a, stream_signed, have_offsets, st);
+    case 1: return launch_decode_convert_t<int8_t>(a, stream_signed, have_offsets, st);
+    case 2: return launch_decode_convert_t<uint16_t>(a, stream_signed, have_offsets, st);
+    case 3: return launch_decode_convert_t<int16_t>(a, stream_signed, have_offsets, st);
+    case 4: return launch_decode_convert_t<uint32_t>(a, stream_signed, have_offsets, st);
+    case 5: return launch_decode_convert_t<int32_t>(a, stream_signed, have_offsets, st);
+    case 6: return launch_decode_convert_t<float>(a, stream_signed, have_offsets, st);
+    case 7: return launch_decode_convert_t<double>(a, stream_signed, have_offsets, st);
     }
     return hipErrorInvalidValue;
 }

@@ -45,6 +45,8 @@ hipError_t launch_encode_generic(int dtype, const EncodeArgs& a, hipStream_t st)
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStream_t st);
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
+// converting decode (decode.hip): any integral output type with clamping, float, double; stream signedness given
+hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st);
 // tuned decode (decode_fast.hip): needs frame offsets, n_values % 4 == 0 and 16-byte aligned pixels_out
 hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st);
 // one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames

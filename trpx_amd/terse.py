@@ -26,11 +26,16 @@ _NP2DT = {np.dtype(np.uint8): _lib.U8, np.dtype(np.int8): _lib.I8, np.dtype(np.u
           np.dtype(np.int16): _lib.I16, np.dtype(np.uint32): _lib.U32, np.dtype(np.int32): _lib.I32}
 
 
-def _code(dt) -> int:
+_NP2DT_OUT = dict(_NP2DT)
+_NP2DT_OUT.update({np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64})
+
+
+def _code(dt, decode: bool = False) -> int:
     try:
-        return _NP2DT[np.dtype(dt)]
+        return (_NP2DT_OUT if decode else _NP2DT)[np.dtype(dt)]
     except KeyError:
-        raise TypeError(f"Terse: unsupported pixel type {dt} (GPU path: u8/i8/u16/i16/u32/i32)") from None
+        raise TypeError(f"Terse: unsupported pixel type {dt} (encode: u8/i8/u16/i16/u32/i32; decode also "
+                        f"float32/float64)") from None
 
 
 class Terse:
@@ -87,18 +92,19 @@ class Terse:
 
     # ---- decode -----------------------------------------------------------------------------
     def prolix(self, out: np.ndarray, frame: int = 0) -> np.ndarray:
-        """Unpack frame `frame` into `out` (Terse.hpp:333-341, :352-389). Same-type decode."""
+        """Unpack frame `frame` into `out` (Terse.hpp:333-341, :352-389).  `out` may have any supported type:
+        narrower integers clamp (Bit_pointer.hpp:747-763), float / double are exact (Terse.hpp:379-383)."""
         if not 0 <= frame < self.number_of_frames():
             raise ValueError("frame index out of range")                                          # Terse.hpp:354
         if out.size != self._size:
             raise ValueError("output container has the wrong size")                               # Terse.hpp:335
-        if self._signed and out.dtype.kind != "i":
+        if self._signed and out.dtype.kind == "u":
             raise ValueError("signed data cannot be decompressed into unsigned data")            # Terse.hpp:356-357
         if not out.flags.c_contiguous:
             raise ValueError("output must be contiguous")
         start = sum(self._frame_sizes[:frame])
         chunk = np.frombuffer(self._data, np.uint8, self._frame_sizes[frame], start).copy()
-        check(lib().trpx_decode_host(int(self._signed), _code(out.dtype), chunk.ctypes.data, chunk.size, None,
+        check(lib().trpx_decode_host(int(self._signed), _code(out.dtype, True), chunk.ctypes.data, chunk.size, None,
                                      self._size, 1, self._block, out.ctypes.data, self._device))
         return out
 
@@ -108,7 +114,7 @@ class Terse:
         out = np.empty((f, self._size), np.dtype(dtype))
         buf = np.frombuffer(self._data, np.uint8)
         offs = np.concatenate([[0], np.cumsum(self._frame_sizes)]).astype(np.uint64)
-        check(lib().trpx_decode_host(int(self._signed), _code(dtype), buf.ctypes.data, buf.size, offs.ctypes.data,
+        check(lib().trpx_decode_host(int(self._signed), _code(dtype, True), buf.ctypes.data, buf.size, offs.ctypes.data,
                                      self._size, f, self._block, out.ctypes.data, self._device))
         return out
 
