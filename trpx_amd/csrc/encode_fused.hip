@@ -188,18 +188,20 @@ __device__ __forceinline__ uint32_t raw_width(const uint32_t (&raw)[Raw<T>::dw])
 // ---------------------------------------------------------------------------------------------
 // OR an ND-dword little-endian bit string (exactly 12*W valid bits, rest zero) into the LDS image
 // at bit position `pos`.  First / last touched dwords may be shared with other lanes.
+// `stage` is the image shifted by one pad dword (image dword i = stage[i + 1]): with rs = -pos mod 32 the string
+// lands in dwords ceil(pos/32)-1 .. +ND, each one funnel shift (v_alignbit) of two neighbouring pieces -- no 64-bit
+// shifts, hence no register-pair constraints on the block's dwords.
 template <int ND>
 __device__ __forceinline__ void lds_or_string(uint32_t* __restrict__ stage, uint32_t pos, const uint32_t (&p)[ND]) {
-    const uint32_t d = pos >> 5, s = pos & 31u, rs = 32u - s;
-    uint32_t prev = 0;
+    const uint32_t d = (pos + 31u) >> 5, rs = (0u - pos) & 31u;
+    atomicOr(&stage[d], __builtin_amdgcn_alignbit(p[0], 0u, rs));              // zero when pos is dword aligned
 #pragma unroll
-    for (int j = 0; j < ND; ++j) {
-        const uint32_t x = (uint32_t)((((uint64_t)p[j] << 32) | prev) >> rs);   // (p[j] << s) | (prev >> (32-s))
-        if (j == 0 || j >= ND - 1) atomicOr(&stage[d + j], x);
+    for (int j = 1; j < ND; ++j) {
+        const uint32_t x = __builtin_amdgcn_alignbit(p[j], p[j - 1], rs);
+        if (j >= ND - 1) atomicOr(&stage[d + j], x);
         else stage[d + j] = x;                              // interior dword: owned by this block alone
-        prev = p[j];
     }
-    const uint32_t x = (uint32_t)(((uint64_t)prev << 32) >> rs >> 32);          // prev >> (32-s), 0 when s == 0
+    const uint32_t x = __builtin_amdgcn_alignbit(0u, p[ND - 1], rs);
     if (x) atomicOr(&stage[d + ND], x);
 }
 
@@ -279,7 +281,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     constexpr int kSub = sub_tiles<T>();
     constexpr int kFusedTileBlocks = kSub * kThreads;
     constexpr int kStage = fused_stage_dwords<T>();
-    __shared__ uint32_t s_stage[kStage];
+    constexpr int kStage4 = (kStage + 1 + 3) / 4;  // in 16-byte units
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage_pad[4 * kStage4];   // [0] = pad dword, always zero (lds_or_string, flush)
+    uint32_t* const s_stage = s_stage_pad + 1;    // the tile-relative bit image
     __shared__ uint32_t s_wtot[kSub * 4];   // bits of each (round, wave) piece without its lane-0 header
     __shared__ uint32_t s_wfl[kSub * 4];    // first width | last width << 8 | lane 0 valid << 16
     __shared__ uint64_t s_excl_bits;       // bits of this frame before the tile
@@ -299,39 +303,65 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     const uint32_t b0 = t * kFusedTileBlocks;
 
     if (tid == 0) s_abort = 0;
-    for (int i = tid; i < kStage; i += kThreads) s_stage[i] = 0u;
+    {                                                                    // zero the image: unrolled ds_write_b128
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        u4* z = reinterpret_cast<u4*>(s_stage_pad);
+#pragma unroll
+        for (int i = 0; i < (kStage4 + kThreads - 1) / kThreads; ++i)
+            if (i * kThreads + (int)tid < kStage4) z[i * kThreads + tid] = (u4)(0u);
+    }
 
     // ---- load, widths, header / payload lengths ------------------------------------------------
+    // Every round's loads are issued back to back and unconditionally (no branch, no register shuffle between
+    // them, so the compiler has no reason to wait for round r before it issues round r+1 -- the per-round
+    // `s_waitcnt vmcnt` of the branchy version made this phase latency bound).  A lane whose block does not exist or
+    // is the frame's partial last block reads the frame's last full block instead; its data are never used.
     uint32_t v[kSub][Raw<T>::dw];
     uint32_t w[kSub], up[kSub], len[kSub], inc[kSub];
     int nb[kSub];
+    const bool has_full = g.n_values >= (uint64_t)kBlock;
+    const uint64_t max_first = has_full ? g.n_values - kBlock : 0;      // vector aligned: n_values % 4 == 0 on this path
+    uint32_t h[Raw<T>::dw];              // block b0-1 (never the frame's last: full), for the tile's first header
+    if (has_full) {
+#pragma unroll
+        for (int r = 0; r < kSub; ++r) {
+            const uint64_t first = (uint64_t)(b0 + r * kThreads + tid) * kBlock;
+            load_raw_nt<T>(fp + (first < max_first ? first : max_first), v[r]);
+        }
+        load_raw_nt<T>(fp + (uint64_t)(b0 ? b0 - 1 : 0) * kBlock, h);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSub; ++r)
+#pragma unroll
+            for (int i = 0; i < Raw<T>::dw; ++i) v[r][i] = 0u;
+#pragma unroll
+        for (int i = 0; i < Raw<T>::dw; ++i) h[i] = 0u;
+    }
 #pragma unroll
     for (int r = 0; r < kSub; ++r) {
         const uint32_t b = b0 + r * kThreads + tid;
         const uint64_t first = (uint64_t)b * kBlock;
-        nb[r] = 0;
-        if (b < g.n_blocks) {
-            if (first + kBlock <= g.n_values) { load_raw_nt<T>(fp + first, v[r]); nb[r] = kBlock; }
-            else { nb[r] = (int)(g.n_values - first); load_raw_partial<T>(fp + first, nb[r], v[r]); }
-        } else {
+        nb[r] = b < g.n_blocks ? (first + kBlock <= g.n_values ? kBlock : (int)(g.n_values - first)) : 0;
+    }
+    // The frame's partial last block (at most one lane of the frame's last tile) lives in its own registers, so that
+    // v[][] stay exactly the registers the vector loads wrote (a merge would put a copy -- and a wait -- behind each load).
+    uint32_t pv[Raw<T>::dw];
 #pragma unroll
-            for (int i = 0; i < Raw<T>::dw; ++i) v[r][i] = 0u;
-        }
+    for (int i = 0; i < Raw<T>::dw; ++i) pv[i] = 0u;
+    if (last_tile_of_frame && g.n_values % kBlock) {
+        const uint32_t bp = g.n_blocks - 1;                             // element loads, missing values read as zero
+        if (bp >= b0 && (bp - b0) % kThreads == tid) load_raw_partial<T>(fp + (uint64_t)bp * kBlock, (int)(g.n_values % kBlock), pv);
     }
+    const uint32_t w_part = raw_width<T>(pv);
     // width of the block before the tile's first block (w_{-1} = 0 at frame start, Terse.hpp:505)
-    uint32_t tile_halo = 0;
-    if (lane == 0 && b0 > 0) {                                           // every wave: it redoes the piece scan itself
-        uint32_t h[Raw<T>::dw];
-        load_raw_nt<T>(fp + (uint64_t)(b0 - 1) * kBlock, h);            // block b0-1 is never the frame's last: full
-        tile_halo = raw_width<T>(h);
-    }
+    const uint32_t tile_halo = b0 > 0 ? raw_width<T>(h) : 0u;           // every wave: it redoes the piece scan itself
     // Lanes 1..63 get the previous block's width from their neighbour; lane 0's header depends on the
     // previous wavefront's last width, so it is left out of the scan here and added after barrier #1.
     uint32_t wmax = 0;
     uint32_t hlr[kSub];                  // header length of lanes 1..63 (lane 0: fixed up after barrier #1)
 #pragma unroll
     for (int r = 0; r < kSub; ++r) {
-        w[r] = nb[r] ? raw_width<T>(v[r]) : 0u;
+        w[r] = nb[r] == kBlock ? raw_width<T>(v[r]) : (nb[r] ? w_part : 0u);
         wmax = w[r] > wmax ? w[r] : wmax;
         if (a.idx_widths && nb[r]) a.idx_widths[(uint64_t)frame * g.n_blocks + b0 + r * kThreads + tid] = (uint8_t)w[r];
         up[r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[r], 0x138, 0xf, 0xf, false);   // wave_shr:1
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
                 const uint64_t hx = (uint64_t)header_val(w[r], wp[r]) << (pos & 31u);
                 atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
                 if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
-                if (w[r] && nb[r] != kBlock) pack_payload_generic<T>(s_stage, pos + hl, w[r], nb[r], v[r]);
+                if (w[r] && nb[r] != kBlock) pack_payload_generic<T>(s_stage, pos + hl, w[r], nb[r], pv);
             }
             // full blocks: one pass per distinct width present in the wavefront, each with static shifts
             uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(nb[r] == kBlock && w[r] != 0u);
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
                 const bool mine = nb[r] == kBlock && w[r] == w0;
 #pragma unroll
                 for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));   // keep the bodies out of LICM's reach
-                if (mine) PackDispatch<T, 1, PixelTraits<T>::bits>::run(s_stage, pos + hl, w0, v[r]);
+                if (mine) PackDispatch<T, 1, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, w0, v[r]);
                 todo &= ~__ballot(mine);
             }
         }
@@ -501,7 +531,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     const bool is_last_tile = tile + 1 == (uint64_t)a.n_frames * a.tiles_per_frame;
     if (tid == 0) {
         const int32_t kt = k_first + (int32_t)n_out;
-        const uint32_t tail_bits = (p_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], kt >= 0 ? s_stage[kt] : 0u, sh) : 0u;
+        const uint32_t tail_bits = (p_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], s_stage[kt], sh) : 0u;
         if (head_pending) {                                              // our share of dword d_first (a tile that does not
             const uint32_t head_bits = __builtin_amdgcn_alignbit(s_stage[0], 0u, sh);   // complete it: all of its bits)
             __hip_atomic_fetch_or(a.tail_desc + tile, kHeadFlag | head_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -514,12 +544,40 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     }
 
     // ---- flush: global dword d_first + j = {image[k+1], image[k]} >> sh, k = j - (s0 != 0) -------------------
-    for (uint32_t j = tid; j < ((TRPX_ABLATE & 4) ? 0u : n_out); j += kThreads) {
-        if (j == 0 && head_pending) continue;                            // the shared first dword: k_stitch
-        const int32_t k = k_first + (int32_t)j;
-        const uint32_t lo = k >= 0 ? s_stage[k] : 0u, hi = s_stage[k + 1];
-        const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, sh);
-        if (writable) __builtin_nontemporal_store(x, a.out32 + d_first + j);
+    // 16-byte groups: one thread turns two aligned ds_read_b128 into one 16-byte aligned non-temporal store (the
+    // image-side misalignment m is tile-uniform: four specialised bodies behind scalar branches).  The <= 7 dwords in
+    // front of / behind the aligned groups go one per thread.
+    if (!(TRPX_ABLATE & 4) && writable) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        uint32_t al = (0u - ((uint32_t)((uintptr_t)a.out32 >> 2) + (uint32_t)d_first)) & 3u;
+        if (head_pending && al == 0) al = 4;                              // dword 0 is k_stitch's: keep it out of the groups
+        al = al < n_out ? al : n_out;
+        const uint32_t n4 = (n_out - al) >> 2, rest0 = al + 4 * n4;
+        if (tid < al + (n_out - rest0)) {
+            const uint32_t j = tid < al ? tid : rest0 + (tid - al);
+            if (!(j == 0 && head_pending)) {
+                const int32_t k = k_first + (int32_t)j;                   // k = -1: the pad dword
+                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(s_stage[k + 1], s_stage[k], sh), a.out32 + d_first + j);
+            }
+        }
+        const uint32_t kk0 = (uint32_t)(k_first + 1) + al;               // s_stage_pad index of the first group's low dword
+        const uint32_t m = kk0 & 3u;
+        const u4* pad4 = reinterpret_cast<const u4*>(s_stage_pad) + (kk0 >> 2);
+        u4* dst = reinterpret_cast<u4*>(a.out32 + d_first + al);
+#define TRPX_FLUSH_GROUPS(M)                                                                                   \
+        for (uint32_t gq = tid; gq < n4; gq += kThreads) {                                                     \
+            const u4 A = pad4[gq], B = pad4[gq + 1];                                                           \
+            const uint32_t e[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};                                    \
+            u4 x;                                                                                              \
+            x.x = __builtin_amdgcn_alignbit(e[M + 1], e[M + 0], sh);                                           \
+            x.y = __builtin_amdgcn_alignbit(e[M + 2], e[M + 1], sh);                                           \
+            x.z = __builtin_amdgcn_alignbit(e[M + 3], e[M + 2], sh);                                           \
+            x.w = __builtin_amdgcn_alignbit(e[M + 4], e[M + 3], sh);                                           \
+            __builtin_nontemporal_store(x, dst + gq);                                                          \
+        }
+        if (m == 0) { TRPX_FLUSH_GROUPS(0) } else if (m == 1) { TRPX_FLUSH_GROUPS(1) }
+        else if (m == 2) { TRPX_FLUSH_GROUPS(2) } else { TRPX_FLUSH_GROUPS(3) }
+#undef TRPX_FLUSH_GROUPS
     }
     TRPX_STAMP(4);
     TRPX_STAMP(5);
