@@ -18,16 +18,17 @@ tiles = frames * tpf
 # workspace layout (api.hip enc_ws): [two-pass arrays][fused descriptors][stamps]
 t256 = frames * ((21846 + 255) // 256)
 fused_off = ((((8 * frames + 15) // 16 * 16) + 8 * t256 + 15) // 16 * 16 + 4 * t256 + 255) // 256 * 256
-stamp_off = fused_off + (8 * (3 * tiles + frames) + 255) // 256 * 256
+stamp_off = fused_off + (8 * (3 * tiles + 18 * frames) + 255) // 256 * 256
 st = ws.buf[stamp_off: stamp_off + 64 * tiles].view(torch.int64).cpu().numpy().reshape(tiles, 8)
 t0 = st[:, 0].min()
-us = (st[:, :6] - t0) / 100.0
-print("kernel span us", us[:, 5].max())
+us = (st[:, :5] - t0) / 100.0      # slots: 0 start, 1 barrier#1, 2 wave-0 look-back done, 3 barrier#2, 4 end; 7 loads issued, 5 wave 0 at barrier#1
+print("kernel span us", us[:, 4].max())
 d = np.diff(us, axis=1)
-names = ["load+scan(->b1)", "lookback(b1->lb)", "lb->b2", "rounds(b2->end)", "tailwait"]
+names = ["load+scan(->b1)", "lookback(b1->lb)", "lb->b2", "flush(b2->end)"]
+print("start->loads issued mean %.2f, ->wave0 scans done mean %.2f" % (((st[:, 7] - st[:, 0]) / 100.0).mean(), ((st[:, 5] - st[:, 0]) / 100.0).mean()))
 for k, nme in enumerate(names):
     print(f"{nme:18s} mean {d[:, k].mean():8.2f} p50 {np.percentile(d[:, k], 50):8.2f} p99 {np.percentile(d[:, k], 99):8.2f} max {d[:, k].max():8.2f}")
-print("tile total       mean", (us[:, 5] - us[:, 0]).mean())
+print("tile total       mean", (us[:, 4] - us[:, 0]).mean())
 # dispatch order: start time vs tile index
 start = us[:, 0]
 inv = (np.diff(start) < -0.5).mean()

@@ -184,7 +184,8 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
         HIP_TRY(trpx::launch_encode_generic(dtype, a, static_cast<hipStream_t>(stream)));
         return TRPX_OK;
     }
-    const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0;
+    const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0 &&
+                        (uint64_t)g.n_blocks * 396 < (1ull << 40);       // frame bits fit the fused encoder's 40-bit accumulator
     if (g_encode_path == 0 && vec_ok)
         HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
     else {

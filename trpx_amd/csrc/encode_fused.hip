@@ -47,6 +47,7 @@ constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seco
 #endif
 
 constexpr uint64_t kStInvalid = 0, kStAgg = 1, kStPrefix = 2;
+constexpr int kWmaxShift = 56;                                           // bnd_pos[tile]: dword index | widest block << 56
 constexpr uint64_t kHeadFlag = 1ull << 63, kTailFlag = 1ull << 62;   // boundary exchange words (k_encode_fused's end, k_stitch)
 __device__ __forceinline__ uint64_t make_desc(uint64_t st, uint64_t v) { return (st << 62) | (v & ((1ull << 62) - 1)); }
 __device__ __forceinline__ uint64_t desc_status(uint64_t d) { return d >> 62; }
@@ -78,20 +79,67 @@ __device__ bool lookback(const uint64_t* __restrict__ desc, int64_t idx, int64_t
     while (pos >= lo) {
         const int64_t my = pos - lane;
         const bool in = my >= lo;
-        uint64_t g = 0;
+        uint64_t g = in ? 0ull : make_desc(kStPrefix, 0);                // below `lo`: prefix 0 ends the chain
         uint32_t first_p = 64;
         uint32_t spins = 0;
+        uint64_t need = ~0ull;
         for (;;) {
-            g = in ? ld_desc(desc + my) : make_desc(kStPrefix, 0);   // below `lo`: prefix 0 ends the chain
+            // re-read only what is still missing AND still matters (lanes behind the nearest prefix never do): the polls
+            // of ~1000 waiting tiles all hit the same few cache lines, i.e. one memory channel
+            if (desc_status(g) == kStInvalid && ((need >> lane) & 1ull)) g = ld_desc(desc + my);
             const uint64_t pmask = __ballot(desc_status(g) == kStPrefix);
             const uint64_t imask = __ballot(desc_status(g) == kStInvalid);
             first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-            const uint64_t need = first_p >= 63u ? ~0ull : ((2ull << first_p) - 1ull);
+            need = first_p >= 63u ? ~0ull : ((2ull << first_p) - 1ull);
             if ((imask & need) == 0) break;
             if (++spins > kSpinLimit) return false;
             __builtin_amdgcn_s_sleep(2);
         }
         acc += wave_sum64((uint32_t)lane <= first_p ? desc_value(g) : 0ull);
+        if (first_p < 64u) break;
+        pos -= 64;
+    }
+    *result = acc;
+    return true;
+}
+
+// Frame chain: byte offset of frame `frame` in the stack = sum of S_f' = 1 + bits(f')/8 (Terse.hpp:547) over the
+// frames before it.  bits(f') is accumulated by the frame's tiles themselves -- each adds {1 << 40 | its bits} to
+// acc[f'] with a fire-and-forget atomic as soon as it knows its size -- so a reader is ONE memory hop behind the
+// slowest contributing tile (a chain of published per-frame sizes would be two).  pref[f'] = {1 << 63 | inclusive
+// bytes} is the shortcut the frame's last tile leaves behind once it knows its own base.
+constexpr int kAccShift = 40;                                            // bits < 2^40, tiles per frame < 2^24
+constexpr uint64_t kPrefFlag = 1ull << 63;
+__device__ bool lookback_frames(const uint64_t* __restrict__ acc_w, const uint64_t* __restrict__ pref_w, int64_t frame,
+                                uint64_t tiles_per_frame, uint64_t* result) {
+    const int lane = lane_id();
+    uint64_t acc = 0;
+    int64_t pos = frame - 1;
+    while (pos >= 0) {
+        const int64_t my = pos - lane;
+        const bool in = my >= 0;
+        uint64_t p = in ? 0ull : kPrefFlag, c = 0;                       // below frame 0: prefix 0 ends the chain
+        uint32_t first_p = 64, spins = 0;
+        uint64_t need = ~0ull;
+        bool complete = false;
+        for (;;) {
+            // re-read only what is still missing and still matters (see lookback)
+            if (in && !(p & kPrefFlag) && !complete && ((need >> lane) & 1ull)) {
+                p = ld_desc(pref_w + my);
+                c = ld_desc(acc_w + my);
+                complete = (c >> kAccShift) == tiles_per_frame;
+            }
+            const uint64_t pmask = __ballot((p & kPrefFlag) != 0);
+            const uint64_t cmask = __ballot(complete);
+            first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+            need = first_p >= 64u ? ~0ull : ((1ull << first_p) - 1ull);  // the lanes in front of the prefix
+            if ((~cmask & need) == 0) break;
+            if (++spins > kSpinLimit) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const uint64_t mine = (uint32_t)lane < first_p ? 1 + (c & ((1ull << kAccShift) - 1)) / 8
+                                                       : ((uint32_t)lane == first_p ? p & ~kPrefFlag : 0ull);
+        acc += wave_sum64(mine);
         if (first_p < 64u) break;
         pos -= 64;
     }
@@ -266,7 +314,9 @@ struct FusedArgs {
     uint64_t* tile_desc;           // [F * tpf]  AGG: tile bits, PREFIX: inclusive bits inside the frame
     uint64_t* tail_desc;           // [F * tpf]  exchange word of the boundary between tile-1 and tile (see the kernel's end)
     uint64_t* bnd_pos;             // [F * tpf]  output dword index of the boundary's shared dword (head side writes it)
-    uint64_t* frame_desc;          // [F]        AGG: S_f bytes, PREFIX: inclusive bytes
+    uint64_t* frame_acc;           // [F]        tiles contributed << 40 | bits of the frame so far (atomic adds)
+    uint64_t* frame_pref;          // [F]        1 << 63 | inclusive bytes through this frame, once known
+    uint64_t* frame_base;          // [F * 16]   1 << 63 | first byte of the frame (one 128-byte line per frame): tile 0 -> the frame's other tiles
     uint64_t* frame_offsets;       // [F + 1]    output
     uint32_t* out32;
     uint32_t* status;
@@ -352,6 +402,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
         const uint32_t bp = g.n_blocks - 1;                             // element loads, missing values read as zero
         if (bp >= b0 && (bp - b0) % kThreads == tid) load_raw_partial<T>(fp + (uint64_t)bp * kBlock, (int)(g.n_values % kBlock), pv);
     }
+    TRPX_STAMP(7);                                                       // loads issued
     const uint32_t w_part = raw_width<T>(pv);
     // width of the block before the tile's first block (w_{-1} = 0 at frame start, Terse.hpp:505)
     const uint32_t tile_halo = b0 > 0 ? raw_width<T>(h) : 0u;           // every wave: it redoes the piece scan itself
@@ -377,16 +428,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
         inc[r + 1] = two >> 16;
     }
     if (kSub & 1) inc[kSub - 1] = wave_inclusive_scan(len[kSub - 1]);
+    const uint32_t wmax_wave = wave_max(wmax);                           // widest block of this wave's 6 x 64
 #pragma unroll
     for (int r = 0; r < kSub; ++r) {
         const uint32_t w_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[r]);
         const uint32_t v_first = (uint32_t)__builtin_amdgcn_readfirstlane(nb[r]);
         if (lane == 63) {
             s_wtot[r * 4 + wave] = inc[r];
-            s_wfl[r * 4 + wave] = w_first | (w[r] << 8) | ((v_first ? 1u : 0u) << 16);
+            s_wfl[r * 4 + wave] = w_first | (w[r] << 8) | ((v_first ? 1u : 0u) << 16) | (r == 0 ? wmax_wave << 24 : 0u);
         }
     }
-    wmax = wave_max(wmax);
+    TRPX_STAMP(5);                                                       // wave 0: data arrived, widths and scans done
     __syncthreads();                                                     // #1: wave totals + staging zeroed
     TRPX_STAMP(1);
 
@@ -420,50 +472,74 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     const uint32_t tile_total = rb[kSub];
 
     // publish this tile's bit count at once (decoupled look-back: nobody waits for our look-back)
-    if (tid == 0 && !(TRPX_DIAG(a) & 1u))
+    if (tid == 0 && !(TRPX_DIAG(a) & 1u)) {
         st_desc(a.tile_desc + tile, make_desc(t == 0 ? kStPrefix : kStAgg, tile_total));
-    // d_prolix_bits (Terse.hpp:516): read first, ~every wave sees a value that is already >= its own
-    if (wmax && lane == 0 && wmax > __hip_atomic_load(&a.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(&a.status[1], wmax);
-
-    // The frame's LAST tile looks back before it packs: every tile of the next frame waits for the S_f it
-    // publishes.  All other tiles pack first (their look-back is then usually satisfied at the first poll).
-    uint64_t early_excl = 0;
-    bool early_ok = true;
-    if (last_tile_of_frame && wave == 0 && t != 0 && !(TRPX_DIAG(a) & 1u)) {
-        early_ok = lookback(a.tile_desc, (int64_t)tile, (int64_t)(tile - t), &early_excl);
-        if (early_ok && lane == 0) {
-            st_desc(a.tile_desc + tile, make_desc(kStPrefix, early_excl + tile_total));
-            st_desc(a.frame_desc + frame, make_desc(kStAgg, 1 + (early_excl + tile_total) / 8));   // S_f (Terse.hpp:547)
-        }
+        __hip_atomic_fetch_add(a.frame_acc + frame, (1ull << kAccShift) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-
+    // d_prolix_bits (Terse.hpp:516): the tile's widest block travels in bnd_pos[tile]'s top bits and k_stitch reduces
+    // them -- an atomicMax per wave on one status word meant ~4000 same-address atomics (~11 ns each, serialised) from
+    // the first wave of tiles, and every wave's next s_waitcnt vmcnt sat behind its own: a ~25 us stall per launch.
     // ---- pack into the tile-relative LDS image, look back meanwhile, flush with a funnel shift ---------
     {
+#ifndef TRPX_ABLATE
+#define TRPX_ABLATE 0
+#endif
+        // headers (and the frame's one partial block), unrolled: short code.  meta[r] = payload bit position | w << 24 |
+        // full block << 31 feeds the payload loop below.
+        uint32_t meta[kSub];
 #pragma unroll
         for (int r = 0; r < kSub; ++r) {
             const uint32_t pos = off[r];
             const uint32_t hl = hlr[r];                                  // (lane 0: from the piece fix-up)
-#ifndef TRPX_ABLATE
-#define TRPX_ABLATE 0
-#endif
             if (nb[r] && !(TRPX_ABLATE & 2)) {
                 const uint64_t hx = (uint64_t)header_val(w[r], wp[r]) << (pos & 31u);
                 atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
                 if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
-                if (w[r] && nb[r] != kBlock) pack_payload_generic<T>(s_stage, pos + hl, w[r], nb[r], pv);
             }
-            // full blocks: one pass per distinct width present in the wavefront, each with static shifts
-            uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(nb[r] == kBlock && w[r] != 0u);
+            meta[r] = (pos + hl) | (w[r] << 24) | (nb[r] == kBlock ? 0x80000000u : 0u);
+        }
+        if (!(TRPX_ABLATE & 2) && last_tile_of_frame && g.n_values % kBlock) {
+            uint32_t pp = 0, wq = 0;
+            int nq = 0;
+#pragma unroll
+            for (int r = 0; r < kSub; ++r)
+                if (nb[r] && nb[r] != kBlock) { pp = meta[r] & 0xFFFFFFu; wq = w[r]; nq = nb[r]; }
+            if (nq && wq) pack_payload_generic<T>(s_stage, pp, wq, nq, pv);
+        }
+        // payloads of the full blocks: one pass per distinct width present in the wavefront, each with static shifts.
+        // (-DTRPX_ROLLED_ROUNDS keeps one copy of the sixteen width bodies instead of one per round: measured, the
+        // smaller code did not shorten the launch's cold start and the register picks cost ~4 % in the steady state.)
+#define TRPX_WSTAMP(slot) do { if ((TRPX_DIAG(a) & 8u) && lane == 0 && tile < 4096) a.stamps[tile * 32 + wave * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+        TRPX_WSTAMP(0);
+#ifdef TRPX_ROLLED_ROUNDS
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+        for (int r = 0; r < ((TRPX_ABLATE & 1) ? 0 : kSub); ++r) {
+            uint32_t m = 0, d[Raw<T>::dw];
+#pragma unroll
+            for (int i = 0; i < Raw<T>::dw; ++i) d[i] = 0;
+#pragma unroll
+            for (int q = 0; q < kSub; ++q)
+                if (r == q) {
+                    m = meta[q];
+#pragma unroll
+                    for (int i = 0; i < Raw<T>::dw; ++i) d[i] = v[q][i];
+                }
+            const uint32_t wr = (m >> 24) & 63u, ppos = m & 0xFFFFFFu;
+            const bool full = (m >> 31) != 0;
+            uint64_t todo = __ballot(full && wr != 0u);
             while (todo) {
                 const int l0 = __builtin_ctzll(todo);
-                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w[r], l0);
-                const bool mine = nb[r] == kBlock && w[r] == w0;
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wr, l0);
+                const bool mine = full && wr == w0;
 #pragma unroll
-                for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));   // keep the bodies out of LICM's reach
-                if (mine) PackDispatch<T, 1, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, w0, v[r]);
+                for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(d[i]));   // keep the bodies out of LICM's reach
+                if (mine) PackDispatch<T, 1, PixelTraits<T>::bits>::run(s_stage_pad, ppos, w0, d);
                 todo &= ~__ballot(mine);
             }
+            TRPX_WSTAMP(1 + r);
         }
 
         // cross-tile prefixes (decoupled look-back), after this wave's share of the packing
@@ -471,12 +547,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
             uint64_t excl = 0;
             bool ok = true;
             if (TRPX_DIAG(a) & 1u) excl = (uint64_t)t * 40000u;
-            else if (last_tile_of_frame) {
-                excl = early_excl;
-                ok = early_ok;
-                if (t == 0 && lane == 0)                                  // single-tile frame
-                    st_desc(a.frame_desc + frame, make_desc(kStAgg, 1 + (uint64_t)tile_total / 8));
-            } else if (t != 0) {
+            else if (t != 0) {
                 ok = lookback(a.tile_desc, (int64_t)tile, (int64_t)(tile - t), &excl);
                 if (ok && lane == 0) st_desc(a.tile_desc + tile, make_desc(kStPrefix, excl + tile_total));
             }
@@ -486,7 +557,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
             uint64_t base = 0;
             bool ok = true;
             if (TRPX_DIAG(a) & 1u) base = (uint64_t)frame * 120000u;
-            else ok = lookback(a.frame_desc, (int64_t)frame, 0, &base);
+            else if (t == 0) {
+                // Only the frame's FIRST tile walks the stack-wide frame chain and hands the result to its siblings
+                // through the frame's own cache line: ~70 pollers on the chain's hot lines instead of ~1000 (requests
+                // to one line are served one by one, ~10 ns each, and the publishing stores queue behind them).
+                ok = lookback_frames(a.frame_acc, a.frame_pref, (int64_t)frame, a.tiles_per_frame, &base);
+                if (ok && lane == 0) st_desc(a.frame_base + (uint64_t)frame * 16, kPrefFlag | base);
+            } else {
+                uint64_t vb = 0;
+                uint32_t spins = 0;
+                for (;;) {
+                    vb = ld_desc(a.frame_base + (uint64_t)frame * 16);   // same address in every lane: one request
+                    if (vb & kPrefFlag) break;
+                    if (++spins > kSpinLimit) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                base = vb & ~kPrefFlag;
+            }
             if (lane == 0) { s_base_bytes = base; if (!ok) s_abort = 1; }
         }
     }
@@ -496,7 +583,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     const uint64_t excl_bits = s_excl_bits, base_bytes = s_base_bytes;
     const uint64_t frame_size = 1 + (excl_bits + tile_total) / 8;        // valid for the frame's last tile
     if (last_tile_of_frame && tid == 0 && !aborted) {
-        st_desc(a.frame_desc + frame, make_desc(kStPrefix, base_bytes + frame_size));
+        st_desc(a.frame_pref + frame, kPrefFlag | (base_bytes + frame_size));
         a.frame_offsets[frame + 1] = base_bytes + frame_size;
         if (frame == 0) a.frame_offsets[0] = 0;
         if (frame + 1 == a.n_frames && align_up(base_bytes + frame_size, 4) > a.out_capacity)
@@ -535,8 +622,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
         if (head_pending) {                                              // our share of dword d_first (a tile that does not
             const uint32_t head_bits = __builtin_amdgcn_alignbit(s_stage[0], 0u, sh);   // complete it: all of its bits)
             __hip_atomic_fetch_or(a.tail_desc + tile, kHeadFlag | head_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.bnd_pos[tile] = d_first;
         }
+        uint32_t wm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wm = (s_wfl[i] >> 24) > wm ? (s_wfl[i] >> 24) : wm;
+        a.bnd_pos[tile] = (head_pending ? d_first : 0ull) | ((uint64_t)wm << kWmaxShift);
         if ((p_end & 31) != 0 && (completed_first || !head_pending)) {   // our share of dword d_last
             if (is_last_tile) { if (writable) __builtin_nontemporal_store(tail_bits, a.out32 + d_last); }
             else __hip_atomic_fetch_or(a.tail_desc + tile + 1, kTailFlag | tail_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -580,21 +670,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
 #undef TRPX_FLUSH_GROUPS
     }
     TRPX_STAMP(4);
-    TRPX_STAMP(5);
     if ((TRPX_DIAG(a) & 4u) && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[blockIdx.x * 8 + 6] = xcc; }
 }
 
-// Stores every dword that two (or, with tiny tiles, more) tiles share: the OR of what they deposited.
+// Stores every dword that two (or, with tiny tiles, more) tiles share: the OR of what they deposited.  Also reduces the
+// tiles' widest-block values into status[1] (d_prolix_bits, Terse.hpp:516): one atomic per workgroup.
 __global__ __launch_bounds__(kThreads) void k_stitch(const uint64_t* __restrict__ xw, const uint64_t* __restrict__ pos,
-                                                     uint64_t n_tiles, uint32_t* __restrict__ out32, uint64_t out_capacity) {
-    const uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x + 1;     // boundary b = between tile b-1 and tile b
-    if (b >= n_tiles) return;
+                                                     uint64_t n_tiles, uint32_t* __restrict__ out32, uint64_t out_capacity,
+                                                     uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_max[4];
+    const uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x;     // tile b; boundary b = between tile b-1 and tile b
+    constexpr uint64_t kPosMask = (1ull << kWmaxShift) - 1;
+    const uint64_t pw = b < n_tiles ? pos[b] : 0ull;
+    const uint32_t wm = wave_max((uint32_t)(pw >> kWmaxShift));
+    if (lane_id() == 0) s_max[wave_id()] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = s_max[0];
+        for (int i = 1; i < 4; ++i) m = s_max[i] > m ? s_max[i] : m;
+        if (m) atomicMax(&status[1], m);
+    }
+    if (b == 0 || b >= n_tiles) return;
     const uint64_t w = xw[b];
     if (!(w & kHeadFlag)) return;                                         // dword-aligned boundary: nothing shared
-    const uint64_t d = pos[b];
-    if ((xw[b - 1] & kHeadFlag) && pos[b - 1] == d && b > 1) return;      // middle of a run (tiny tiles): its first boundary stores
+    const uint64_t d = pw & kPosMask;
+    if ((xw[b - 1] & kHeadFlag) && (pos[b - 1] & kPosMask) == d && b > 1) return;   // middle of a run (tiny tiles): its first boundary stores
     uint32_t acc = (uint32_t)w;
-    for (uint64_t k = b + 1; k < n_tiles && (xw[k] & kHeadFlag) && pos[k] == d; ++k) acc |= (uint32_t)xw[k];
+    for (uint64_t k = b + 1; k < n_tiles && (xw[k] & kHeadFlag) && (pos[k] & kPosMask) == d; ++k) acc |= (uint32_t)xw[k];
     if (4 * d + 4 <= out_capacity) out32[d] = acc;
 }
 
@@ -606,7 +708,7 @@ static uint32_t fused_tiles_per_frame(const FrameGeom& g) {
 
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     const size_t tpf = ((size_t)g.n_blocks + 2 * kThreads - 1) / (2 * kThreads);   // finest tiling (32-bit pixels)
-    return align_up(8 * (3 * n_frames * tpf + n_frames), 256) + 64 * n_frames * tpf;   // + diagnostic stamps
+    return align_up(8 * (3 * n_frames * tpf + 18 * n_frames), 256) + 64 * n_frames * tpf;   // + diagnostic stamps
 }
 
 template <typename T>
@@ -620,13 +722,15 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     a.tile_desc = static_cast<uint64_t*>(ws);
     a.tail_desc = a.tile_desc + tiles;
     a.bnd_pos = a.tail_desc + tiles;
-    a.frame_desc = a.bnd_pos + tiles;
+    a.frame_acc = a.bnd_pos + tiles;
+    a.frame_pref = a.frame_acc + e.n_frames;
+    a.frame_base = a.frame_pref + e.n_frames;
     a.frame_offsets = e.frame_offsets;
     a.out32 = reinterpret_cast<uint32_t*>(e.out);
     a.status = e.status;
     a.idx_widths = e.idx_widths;
     a.idx_group_off = e.idx_group_off;
-    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + e.n_frames), 256));
+    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + 18 * e.n_frames), 256));
 #ifdef TRPX_DIAGNOSTICS
     a.debug = getenv("TRPX_FUSED_DEBUG") ? (uint32_t)atoi(getenv("TRPX_FUSED_DEBUG")) : 0u;
 #else
@@ -637,14 +741,13 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     prof.mark(st);
     // every polled / OR-ed word and the status block, cleared on every call (see k_zero_words)
     hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
-                       (uint64_t)(3 * tiles + e.n_frames), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
+                       (uint64_t)(3 * tiles + 18 * e.n_frames), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
     prof.mark(st);
     hipLaunchKernelGGL((k_encode_fused<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, st,
                        static_cast<const T*>(e.pixels), a);
     prof.mark(st);
-    if (tiles > 1)
-        hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles - 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                           a.tail_desc, a.bnd_pos, (uint64_t)tiles, a.out32, (uint64_t)e.out_capacity);
+    hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       a.tail_desc, a.bnd_pos, (uint64_t)tiles, a.out32, (uint64_t)e.out_capacity, a.status);
     prof.mark(st);
     return hipGetLastError();
 }
