@@ -47,6 +47,7 @@ constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seco
 #endif
 
 constexpr uint64_t kStInvalid = 0, kStAgg = 1, kStPrefix = 2;
+constexpr uint32_t kGridY = 32768;                                      // frames per grid.z slice
 constexpr int kWmaxShift = 56;                                           // bnd_pos[tile]: dword index | widest block << 56
 constexpr uint64_t kHeadFlag = 1ull << 63, kTailFlag = 1ull << 62;   // boundary exchange words (k_encode_fused's end, k_stitch)
 __device__ __forceinline__ uint64_t make_desc(uint64_t st, uint64_t v) { return (st << 62) | (v & ((1ull << 62) - 1)); }
@@ -341,25 +342,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
     __shared__ uint32_t s_abort;
 
     const uint32_t tid = threadIdx.x;
-#define TRPX_STAMP(slot) do { if ((TRPX_DIAG(a) & 4u) && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TRPX_STAMP(slot) do { if ((TRPX_DIAG(a) & 4u) && threadIdx.x == 0) a.stamps[((uint64_t)(blockIdx.z * kGridY + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TRPX_STAMP(0);
     const int lane = lane_id(), wave = wave_id();
     const FrameGeom g = a.g;
-    const uint64_t tile = blockIdx.x;
-    const uint32_t frame = (uint32_t)(tile / a.tiles_per_frame);
-    const uint32_t t = (uint32_t)(tile % a.tiles_per_frame);
-    const bool last_tile_of_frame = t + 1 == a.tiles_per_frame;
+    // grid = (tiles per frame, frames in chunks of kGridY): x runs fastest, so the linear dispatch order is tile order
+    const uint32_t t = blockIdx.x;
+    const uint32_t frame = blockIdx.z * kGridY + blockIdx.y;
+    const uint32_t n_frames = a.n_frames, tpf = a.tiles_per_frame;
+    asm volatile("" :: "s"(g.n_values), "s"(g.n_blocks), "s"(n_frames), "s"(tpf), "s"(pixels));   // one kernarg fetch, one wait
+    if (frame >= n_frames) return;
+    const uint64_t tile = (uint64_t)frame * tpf + t;
+    const bool last_tile_of_frame = t + 1 == tpf;
     const T* fp = pixels + (uint64_t)frame * g.n_values;
     const uint32_t b0 = t * kFusedTileBlocks;
-
-    if (tid == 0) s_abort = 0;
-    {                                                                    // zero the image: unrolled ds_write_b128
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        u4* z = reinterpret_cast<u4*>(s_stage_pad);
-#pragma unroll
-        for (int i = 0; i < (kStage4 + kThreads - 1) / kThreads; ++i)
-            if (i * kThreads + (int)tid < kStage4) z[i * kThreads + tid] = (u4)(0u);
-    }
 
     // ---- load, widths, header / payload lengths ------------------------------------------------
     // Every round's loads are issued back to back and unconditionally (no branch, no register shuffle between
@@ -392,6 +388,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
         const uint32_t b = b0 + r * kThreads + tid;
         const uint64_t first = (uint64_t)b * kBlock;
         nb[r] = b < g.n_blocks ? (first + kBlock <= g.n_values ? kBlock : (int)(g.n_values - first)) : 0;
+    }
+    if (tid == 0) s_abort = 0;
+    {                                                                    // zero the image: unrolled ds_write_b128
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        u4* z = reinterpret_cast<u4*>(s_stage_pad);
+#pragma unroll
+        for (int i = 0; i < (kStage4 + kThreads - 1) / kThreads; ++i)
+            if (i * kThreads + (int)tid < kStage4) z[i * kThreads + tid] = (u4)(0u);
     }
     // The frame's partial last block (at most one lane of the frame's last tile) lives in its own registers, so that
     // v[][] stay exactly the registers the vector loads wrote (a merge would put a copy -- and a wait -- behind each load).
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
 #undef TRPX_FLUSH_GROUPS
     }
     TRPX_STAMP(4);
-    if ((TRPX_DIAG(a) & 4u) && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[blockIdx.x * 8 + 6] = xcc; }
+    if ((TRPX_DIAG(a) & 4u) && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[tile * 8 + 6] = xcc; }
 }
 
 // Stores every dword that two (or, with tiny tiles, more) tiles share: the OR of what they deposited.  Also reduces the
@@ -743,7 +747,8 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
                        (uint64_t)(3 * tiles + 18 * e.n_frames), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
     prof.mark(st);
-    hipLaunchKernelGGL((k_encode_fused<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL((k_encode_fused<T>), dim3(a.tiles_per_frame, e.n_frames < kGridY ? e.n_frames : kGridY, (e.n_frames + kGridY - 1) / kGridY),
+                       dim3(kThreads), 0, st,
                        static_cast<const T*>(e.pixels), a);
     prof.mark(st);
     hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
