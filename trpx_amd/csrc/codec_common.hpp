@@ -95,7 +95,9 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+// wave index as a SCALAR (readfirstlane): branches on it are uniform, so whatever a single wave computes from
+// wave-uniform values stays in SGPRs / on the scalar unit instead of being treated as divergent per-lane data
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Workgroup-wide exclusive scan of one u32 per thread (256 threads = 4 waves).
 // `wave_tot` is a 4-entry LDS array.  Returns the exclusive prefix; *total gets the tile sum.
