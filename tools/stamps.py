@@ -6,7 +6,7 @@ import numpy as np, torch
 from trpx_amd import codec, _lib
 L = _lib.lib()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-TB = int(os.environ.get("TRPX_TILE_BLOCKS", "1536"))
+TB = int(os.environ.get("TRPX_TILE_BLOCKS", "1024"))
 n = 512 * 512
 px = codec.synth(np.uint16, 0, frames, n)
 ws = codec.Workspace("cuda")

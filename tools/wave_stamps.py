@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, os.getcwd())
 os.environ["TRPX_FUSED_DEBUG"] = "8"
 import numpy as np, torch
 from trpx_amd import codec
-frames = 2000; TB = 1536; n = 512 * 512
+frames = 2000; TB = 1024; n = 512 * 512
 px = codec.synth(np.uint16, 0, frames, n)
 ws = codec.Workspace("cuda")
 for _ in range(3): enc = codec.encode(px, workspace=ws)

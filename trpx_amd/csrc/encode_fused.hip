@@ -30,11 +30,12 @@
 
 namespace trpx {
 
-// sub-tiles per tile: 6 (1536 blocks) for 8/16-bit pixels, 3 (768 blocks) for 32-bit pixels: the worst-case LDS
-// image of a whole tile is then ~39 KB (4 workgroups per CU).  Measured sweep, 2000 x 512^2 u16: 2/3/4/5/6/8
-// sub-tiles -> 0.66/0.59/0.54/0.53/0.48/0.56 ms; 4096^2 i32: 2/3/4 -> 0.28/0.24/0.24 ms (bigger tiles amortise
-// the per-tile scans and look-backs; beyond 6 the occupancy loss wins).
-template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 6 : 3; }
+// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels at 6 workgroups per CU (26 KB worst-case LDS image, 64 VGPRs),
+// 3 (768 blocks) for 32-bit pixels at 4 per CU (38 KB).  Measured with the final chain design, 2000 x 512^2 u16:
+// 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms; 4096^2 i32:
+// 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
+template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
+template <typename T> constexpr int fused_occupancy() { return sizeof(T) <= 2 ? 6 : 4; }   // workgroups per CU (LDS image + VGPR budget)
 constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seconds), then give up
 
 // Diagnostics (tools/stamps.py, tools/enc_time.py): only in builds with -DTRPX_DIAGNOSTICS; the product build folds
@@ -240,50 +241,80 @@ __device__ __forceinline__ uint32_t raw_width(const uint32_t (&raw)[Raw<T>::dw])
 // `stage` is the image shifted by one pad dword (image dword i = stage[i + 1]): with rs = -pos mod 32 the string
 // lands in dwords ceil(pos/32)-1 .. +ND, each one funnel shift (v_alignbit) of two neighbouring pieces -- no 64-bit
 // shifts, hence no register-pair constraints on the block's dwords.
+// The block's header rides along: `hv_top` holds the header code in its TOP bits (the code's last bit in bit 31), i.e.
+// it is the 32-bit piece in front of the payload string, so the header costs one more funnel shift instead of a
+// 64-bit shift, an address and two atomics of its own.
 template <int ND>
-__device__ __forceinline__ void lds_or_string(uint32_t* __restrict__ stage, uint32_t pos, const uint32_t (&p)[ND]) {
+__device__ __forceinline__ void lds_or_string(uint32_t* __restrict__ stage, uint32_t pos, uint32_t hv_top,
+                                              const uint32_t* __restrict__ p) {
     const uint32_t d = (pos + 31u) >> 5, rs = (0u - pos) & 31u;
-    atomicOr(&stage[d], __builtin_amdgcn_alignbit(p[0], 0u, rs));              // zero when pos is dword aligned
+    const uint32_t xm = __builtin_amdgcn_alignbit(hv_top, 0u, rs);              // header bits below the payload's first dword
+    if (xm) atomicOr(&stage[d - 1], xm);
+    if constexpr (ND == 0) {
+        const uint32_t x0 = __builtin_amdgcn_alignbit(0u, hv_top, rs);
+        if (x0) atomicOr(&stage[d], x0);
+    } else {
+        atomicOr(&stage[d], __builtin_amdgcn_alignbit(p[0], hv_top, rs));
 #pragma unroll
-    for (int j = 1; j < ND; ++j) {
-        const uint32_t x = __builtin_amdgcn_alignbit(p[j], p[j - 1], rs);
-        if (j >= ND - 1) atomicOr(&stage[d + j], x);
-        else stage[d + j] = x;                              // interior dword: owned by this block alone
+        for (int j = 1; j < ND; ++j) {
+            const uint32_t x = __builtin_amdgcn_alignbit(p[j], p[j - 1], rs);
+            if (j >= ND - 1) atomicOr(&stage[d + j], x);
+            else stage[d + j] = x;                          // interior dword: owned by this block alone
+        }
+        const uint32_t x = __builtin_amdgcn_alignbit(0u, p[ND - 1], rs);
+        if (x) atomicOr(&stage[d + ND], x);
     }
-    const uint32_t x = __builtin_amdgcn_alignbit(0u, p[ND - 1], rs);
-    if (x) atomicOr(&stage[d + ND], x);
 }
 
 template <typename T, int W>
-__device__ __forceinline__ void pack_payload_w(uint32_t* __restrict__ stage, uint32_t pos,
+__device__ __forceinline__ void pack_payload_w(uint32_t* __restrict__ stage, uint32_t pos, uint32_t hv_top,
                                                const uint32_t (&raw)[Raw<T>::dw]) {
     constexpr int NB = kBlock * W;
     constexpr int ND = (NB + 31) / 32;
     constexpr int per = Raw<T>::per, bits = Raw<T>::bits;
     constexpr uint32_t MASK = W >= 32 ? 0xFFFFFFFFu : ((1u << (W & 31)) - 1u);
-    uint32_t p[ND];
+    uint32_t p[ND ? ND : 1];
 #pragma unroll
     for (int j = 0; j < ND; ++j) p[j] = 0;
+    if constexpr (W == 0) {
+    } else if constexpr (bits == 16) {
+        // two values per dword: y = lo | hi << W in two operations (shift, v_bfi), then 2W-bit pieces
+        constexpr uint32_t kPairMask = 2 * W >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * W) & 31)) - 1u);
 #pragma unroll
-    for (int k = 0; k < kBlock; ++k) {
-        const uint32_t u = (raw[k / per] >> ((k % per) * bits)) & MASK;   // value mod 2^W (Bit_pointer.hpp:707-710)
-        const int bit = k * W;
-        p[bit >> 5] |= u << (bit & 31);
-        if ((bit & 31) + W > 32) p[(bit >> 5) + 1] |= u >> (32 - (bit & 31));
+        for (int j = 0; j < kBlock / 2; ++j) {
+            const uint32_t x = raw[j];
+            uint32_t y = x;
+            if constexpr (W < 16) {
+                const uint32_t t = x >> (16 - W);
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(MASK), "v"(x), "v"(t));   // (x & MASK) | (t & ~MASK)
+                if (PixelTraits<T>::is_signed) y &= kPairMask;                        // sign bits above the fields
+            }
+            const int bit = 2 * W * j;
+            p[bit >> 5] |= y << (bit & 31);
+            if ((bit & 31) + 2 * W > 32) p[(bit >> 5) + 1] |= y >> (32 - (bit & 31));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kBlock; ++k) {
+            const uint32_t u = (raw[k / per] >> ((k % per) * bits)) & MASK;   // value mod 2^W (Bit_pointer.hpp:707-710)
+            const int bit = k * W;
+            p[bit >> 5] |= u << (bit & 31);
+            if ((bit & 31) + W > 32) p[(bit >> 5) + 1] |= u >> (32 - (bit & 31));
+        }
     }
-    lds_or_string<ND>(stage, pos, p);
+    lds_or_string<ND>(stage, pos, hv_top, p);
 }
 
 // Binary dispatch on a wave-uniform width (scalar compares only, one specialised body executes).
 template <typename T, int LO, int HI>
 struct PackDispatch {
-    static __device__ __forceinline__ void run(uint32_t* stage, uint32_t pos, uint32_t w0,
+    static __device__ __forceinline__ void run(uint32_t* stage, uint32_t pos, uint32_t hv_top, uint32_t w0,
                                                const uint32_t (&raw)[Raw<T>::dw]) {
-        if constexpr (LO == HI) pack_payload_w<T, LO>(stage, pos, raw);
+        if constexpr (LO == HI) pack_payload_w<T, LO>(stage, pos, hv_top, raw);
         else {
             constexpr int MID = (LO + HI) / 2;
-            if (w0 <= (uint32_t)MID) PackDispatch<T, LO, MID>::run(stage, pos, w0, raw);
-            else PackDispatch<T, MID + 1, HI>::run(stage, pos, w0, raw);
+            if (w0 <= (uint32_t)MID) PackDispatch<T, LO, MID>::run(stage, pos, hv_top, w0, raw);
+            else PackDispatch<T, MID + 1, HI>::run(stage, pos, hv_top, w0, raw);
         }
     }
 };
@@ -328,13 +359,14 @@ struct FusedArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restrict__ pixels, FusedArgs a) {
+__global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused(const T* __restrict__ pixels, FusedArgs a) {
     constexpr int kSub = sub_tiles<T>();
     constexpr int kFusedTileBlocks = kSub * kThreads;
     constexpr int kStage = fused_stage_dwords<T>();
     constexpr int kStage4 = (kStage + 1 + 3) / 4;  // in 16-byte units
     __shared__ __attribute__((aligned(16))) uint32_t s_stage_pad[4 * kStage4];   // [0] = pad dword, always zero (lds_or_string, flush)
     uint32_t* const s_stage = s_stage_pad + 1;    // the tile-relative bit image
+    __shared__ uint32_t s_hdr[40];          // explicit header code of width w, top aligned (see lds_or_string)
     __shared__ uint32_t s_wtot[kSub * 4];   // bits of each (round, wave) piece without its lane-0 header
     __shared__ uint32_t s_wfl[kSub * 4];    // first width | last width << 8 | lane 0 valid << 16
     __shared__ uint64_t s_excl_bits;       // bits of this frame before the tile
@@ -390,6 +422,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
         nb[r] = b < g.n_blocks ? (first + kBlock <= g.n_values ? kBlock : (int)(g.n_values - first)) : 0;
     }
     if (tid == 0) s_abort = 0;
+    if (tid <= 32u) s_hdr[tid] = header_val(tid, tid + 1u) << (32u - header_len(tid, tid + 1u));
     {                                                                    // zero the image: unrolled ds_write_b128
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         u4* z = reinterpret_cast<u4*>(s_stage_pad);
@@ -480,6 +513,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
         st_desc(a.tile_desc + tile, make_desc(t == 0 ? kStPrefix : kStAgg, tile_total));
         __hip_atomic_fetch_add(a.frame_acc + frame, (1ull << kAccShift) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // (Reading the chains' first windows before the packing, to hide their round trip, was measured: 0.326 -> 0.396 ms --
+    // early reads mostly miss and every extra request on the chains' hot lines delays the stores that publish them.)
     // d_prolix_bits (Terse.hpp:516): the tile's widest block travels in bnd_pos[tile]'s top bits and k_stitch reduces
     // them -- an atomicMax per wave on one status word meant ~4000 same-address atomics (~11 ns each, serialised) from
     // the first wave of tiles, and every wave's next s_waitcnt vmcnt sat behind its own: a ~25 us stall per launch.
@@ -488,59 +523,31 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_fused(const T* __restric
 #ifndef TRPX_ABLATE
 #define TRPX_ABLATE 0
 #endif
-        // headers (and the frame's one partial block), unrolled: short code.  meta[r] = payload bit position | w << 24 |
-        // full block << 31 feeds the payload loop below.
-        uint32_t meta[kSub];
+        // Full blocks: header + payload as ONE bit string, one pass per distinct width present in the wavefront (w = 0:
+        // the header alone), each with static shifts.  The frame's partial last block goes the generic way.
+#define TRPX_WSTAMP(slot) do { if ((TRPX_DIAG(a) & 8u) && lane == 0 && tile < 4096) a.stamps[tile * 32 + wave * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+        TRPX_WSTAMP(0);
 #pragma unroll
         for (int r = 0; r < kSub; ++r) {
             const uint32_t pos = off[r];
             const uint32_t hl = hlr[r];                                  // (lane 0: from the piece fix-up)
-            if (nb[r] && !(TRPX_ABLATE & 2)) {
-                const uint64_t hx = (uint64_t)header_val(w[r], wp[r]) << (pos & 31u);
+            const uint32_t wr = w[r];
+            const uint32_t hv_top = wr == wp[r] ? 0x80000000u : s_hdr[wr];   // header code, top aligned (Terse.hpp:517-535)
+            const bool full = nb[r] == kBlock;
+            if (nb[r] && !full && !(TRPX_ABLATE & 2)) {
+                const uint64_t hx = (uint64_t)(hv_top >> (32u - hl)) << (pos & 31u);
                 atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
                 if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
+                if (wr) pack_payload_generic<T>(s_stage, pos + hl, wr, nb[r], pv);
             }
-            meta[r] = (pos + hl) | (w[r] << 24) | (nb[r] == kBlock ? 0x80000000u : 0u);
-        }
-        if (!(TRPX_ABLATE & 2) && last_tile_of_frame && g.n_values % kBlock) {
-            uint32_t pp = 0, wq = 0;
-            int nq = 0;
-#pragma unroll
-            for (int r = 0; r < kSub; ++r)
-                if (nb[r] && nb[r] != kBlock) { pp = meta[r] & 0xFFFFFFu; wq = w[r]; nq = nb[r]; }
-            if (nq && wq) pack_payload_generic<T>(s_stage, pp, wq, nq, pv);
-        }
-        // payloads of the full blocks: one pass per distinct width present in the wavefront, each with static shifts.
-        // (-DTRPX_ROLLED_ROUNDS keeps one copy of the sixteen width bodies instead of one per round: measured, the
-        // smaller code did not shorten the launch's cold start and the register picks cost ~4 % in the steady state.)
-#define TRPX_WSTAMP(slot) do { if ((TRPX_DIAG(a) & 8u) && lane == 0 && tile < 4096) a.stamps[tile * 32 + wave * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-        TRPX_WSTAMP(0);
-#ifdef TRPX_ROLLED_ROUNDS
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
-        for (int r = 0; r < ((TRPX_ABLATE & 1) ? 0 : kSub); ++r) {
-            uint32_t m = 0, d[Raw<T>::dw];
-#pragma unroll
-            for (int i = 0; i < Raw<T>::dw; ++i) d[i] = 0;
-#pragma unroll
-            for (int q = 0; q < kSub; ++q)
-                if (r == q) {
-                    m = meta[q];
-#pragma unroll
-                    for (int i = 0; i < Raw<T>::dw; ++i) d[i] = v[q][i];
-                }
-            const uint32_t wr = (m >> 24) & 63u, ppos = m & 0xFFFFFFu;
-            const bool full = (m >> 31) != 0;
-            uint64_t todo = __ballot(full && wr != 0u);
+            uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(full);
             while (todo) {
                 const int l0 = __builtin_ctzll(todo);
                 const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wr, l0);
                 const bool mine = full && wr == w0;
 #pragma unroll
-                for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(d[i]));   // keep the bodies out of LICM's reach
-                if (mine) PackDispatch<T, 1, PixelTraits<T>::bits>::run(s_stage_pad, ppos, w0, d);
+                for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));   // keep the bodies out of LICM's reach
+                if (mine) PackDispatch<T, 0, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, hv_top, w0, v[r]);
                 todo &= ~__ballot(mine);
             }
             TRPX_WSTAMP(1 + r);
