@@ -23,7 +23,16 @@
 
 namespace trpx {
 
-constexpr int kStepGroups = 12;                        // 64-block groups per super-step (kStepGroups / 3 per unpack wave)
+#ifndef TRPX_FRAME_WAVES
+#define TRPX_FRAME_WAVES 4
+#endif
+#ifndef TRPX_FRAME_GPW
+#define TRPX_FRAME_GPW 4
+#endif
+constexpr int kFrameWaves = TRPX_FRAME_WAVES;           // waves per workgroup: 1 walker + (kFrameWaves - 1) unpackers
+constexpr int kFrameThreads = kFrameWaves * kWave;
+constexpr int kGroupsPerWave = TRPX_FRAME_GPW;          // 64-block groups per unpack wave and super-step
+constexpr int kStepGroups = (kFrameWaves - 1) * kGroupsPerWave;   // 64-block groups per super-step
 constexpr int kStepBlocks = kStepGroups * kWave;       // 384
 constexpr int kFrameChunkDw = 2048;                    // walker's stream window: 8 KB
 
@@ -31,16 +40,13 @@ template <typename T>
 constexpr int group_image_dwords() { return (kWave * max_block_bits<T>() + 31) / 32 + 12; }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads, 8) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
-    constexpr int kGImg = group_image_dwords<T>();
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
     __shared__ uint32_t s_chunk[kFrameChunkDw + 4];    // walker's window of the stream
-    __shared__ uint32_t s_gimg[3][kGImg];              // one group image per unpack wave
-    __shared__ uint8_t s_w[2][kStepBlocks];            // widths of the super-step's blocks (double buffered)
+    __shared__ uint8_t s_w[2][kStepBlocks + 4];        // [0] = width of the block before the super-step, [1 + i] = widths of its blocks (double buffered)
     __shared__ uint32_t s_goff[2][kStepGroups];        // frame-relative bit offset of each group's first block
-    __shared__ uint32_t s_whalo[2];                    // width of the block before the super-step
     __shared__ uint32_t s_err;
 
     const uint32_t lane = (uint32_t)lane_id();
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_decode_frames(const uint8_t* __
             if (s < n_steps) {
                 const uint32_t buf = s & 1u;
                 const uint32_t end_b = (s + 1) * kStepBlocks < n_blocks ? (s + 1) * kStepBlocks : n_blocks;
-                if (lane == 0) s_whalo[buf] = w_prev;
+                if (lane == 0) s_w[buf][0] = (uint8_t)w_prev;
                 bool bad = false;
                 while (b < end_b) {
                     const uint32_t stride = 1u + kBlock * w_prev;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_decode_frames(const uint8_t* __
                     }
                     const uint32_t n_done = new_b - b, rel = b - s * kStepBlocks;
                     if (lane < n_done) {
-                        s_w[buf][rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
+                        s_w[buf][1 + rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
                         if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + lane * stride;
                     }
                     pos = new_pos;
@@ -144,66 +150,73 @@ __global__ __launch_bounds__(kThreads, 8) void k_decode_frames(const uint8_t* __
                 if (bad && lane == 0) s_err = 1u;
             }
         } else if (s >= 1) {
-            // ---- unpack super-step s-1: this wave's two groups, one after the other ------------------------------
-            // (fetching both groups first needs a second set of per-lane state: 64+ VGPRs, spills, measured slower)
+            // ---- unpack super-step s-1: this wave's groups, one after the other ------------------------------------
+            // Every lane loads the stream dwords of its own block straight from L2 (the walker has just pulled them
+            // through): one or more dwordx4 loads starting at the dword that holds the block's first payload bit, as many
+            // as the widest block of the group needs; the width-specialised bodies then work on registers only.
             const uint32_t pbuf = (s - 1) & 1u;
-            uint32_t* __restrict__ img = s_gimg[wave - 1];
+            constexpr int NQ = RawQuads<T>::n;
+            const uint32_t* __restrict__ fbase = s32 + frame_dw;          // wave-uniform base; per-lane 32-bit dword offsets
 #pragma unroll 1
-            for (int gq = 0; gq < kStepGroups / 3; ++gq) {
-                const uint32_t gi = (uint32_t)(wave - 1) * (uint32_t)(kStepGroups / 3) + gq;
+            for (int gq = 0; gq < kGroupsPerWave; ++gq) {
+                const uint32_t gi = (uint32_t)(wave - 1) * (uint32_t)kGroupsPerWave + gq;
                 const uint32_t rel = gi * kWave + lane;
                 const uint32_t blk = (s - 1) * kStepBlocks + rel;
                 if ((s - 1) * kStepBlocks + gi * kWave >= n_blocks) break;            // wave-uniform: group past the frame's end
                 uint32_t w = 0, hl = 0;
                 int nb = 0;
                 if (blk < n_blocks) {
-                    w = s_w[pbuf][rel];
-                    const uint32_t wp = rel ? s_w[pbuf][rel - 1] : s_whalo[pbuf];
+                    w = s_w[pbuf][1 + rel];
+                    const uint32_t wp = s_w[pbuf][rel];
                     hl = header_len(w, wp);
                     nb = blk + 1 == n_blocks ? (int)nb_last : kBlock;
                 }
-                const uint32_t len = nb ? hl + (uint32_t)nb * w : 0u;
+                const uint32_t len = nb ? hl + __umul24((uint32_t)nb, w) : 0u;
                 const uint32_t inc = wave_inclusive_scan(len);
-                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                const uint64_t a0 = frame_abit + s_goff[pbuf][gi];                    // absolute bit of the group's first bit
-                const uint64_t d_lo = (a0 >> 5) & ~3ull;
-                const uint32_t n_need = (uint32_t)(((a0 + total + 31) >> 5) - d_lo) + 1;
-                for (uint32_t i = lane * 4; i < n_need && i < (uint32_t)kGImg - 4; i += kWave * 4) {
-                    const uint64_t d = d_lo + i;
-                    uint4 x;
-                    if (base16 && d + 4 <= n_dw) x = *reinterpret_cast<const uint4*>(s32 + d);
-                    else {
-                        x.x = d < n_dw ? s32[d] : 0u; x.y = d + 1 < n_dw ? s32[d + 1] : 0u;
-                        x.z = d + 2 < n_dw ? s32[d + 2] : 0u; x.w = d + 3 < n_dw ? s32[d + 3] : 0u;
-                    }
-                    *reinterpret_cast<uint4*>(&img[i]) = x;
-                }
-                const uint32_t q = (uint32_t)(a0 - 32 * d_lo) + (inc - len) + hl;     // first payload bit in the image
-                uint32_t u[kBlock];
+                const uint32_t q = frame_sh + s_goff[pbuf][gi] + (inc - len) + hl;    // first payload bit, relative to dword frame_dw
+                const uint32_t dq = q >> 5, sq = q & 31u;
+                // All NQ quads, whatever the widths: a 16-byte load more per lane is cheaper than a wavefront max of the
+                // widths, and the extra bytes are the neighbours' (same cache lines).
+                const uint32_t last_dw = (uint32_t)__builtin_amdgcn_readlane((int)dq, 63) + 4u * NQ;   // lanes ascend in position
+                uint32_t raw[4 * NQ];
+                if (frame_dw + last_dw <= n_dw) {                                     // wave-uniform: the loads stay inside the stream
 #pragma unroll
-                for (int k = 0; k < kBlock; ++k) u[k] = 0u;                            // w == 0 -> zeros (Terse.hpp:373-374)
-                uint64_t todo = __ballot(nb == kBlock && w != 0u);
+                    for (int i = 0; i < NQ; ++i) {
+                        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                        u4 x4;
+                        __builtin_memcpy(&x4, fbase + dq + 4 * i, 16);                 // dword-aligned 16-byte load
+                        raw[4 * i] = x4.x; raw[4 * i + 1] = x4.y; raw[4 * i + 2] = x4.z; raw[4 * i + 3] = x4.w;
+                    }
+                } else {                                                              // the stack's last bytes: guarded element loads
+#pragma unroll
+                    for (int i = 0; i < 4 * NQ; ++i) {
+                        const uint64_t d = frame_dw + dq + i;
+                        raw[i] = d < n_dw ? s32[d] : 0u;
+                    }
+                }
+                T* __restrict__ dst = fout + (uint64_t)blk * kBlock;
+                uint64_t todo = __ballot(nb == kBlock);
                 while (todo) {
                     const int l0 = __builtin_ctzll(todo);
                     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
                     const bool mine = nb == kBlock && w == w0;
-                    uint32_t qq = q;
-                    asm volatile("" : "+v"(qq));                                      // keep the specialised bodies out of LICM's reach
-                    if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(img, qq, w0, u);
+                    uint32_t ss = sq;
+                    asm volatile("" : "+v"(ss));                                      // keep the specialised bodies out of LICM's reach
+                    if (mine) UnpackStoreDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, dst);
                     todo &= ~__ballot(mine);
                 }
-                if (nb == kBlock) store_block<T>(fout + (uint64_t)blk * kBlock, u);
-                else if (nb) {                                                        // the frame's last, partial block
+                if (nb && nb != kBlock) {                                             // the frame's last, partial block
                     const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
                     uint32_t p = q;
                     for (int k = 0; k < nb; ++k) {
                         uint32_t f = 0;
                         if (w) {
-                            const uint64_t two = (uint64_t)img[p >> 5] | ((uint64_t)img[(p >> 5) + 1] << 32);
+                            const uint64_t d = frame_dw + (p >> 5);
+                            const uint64_t two = (uint64_t)(d < n_dw ? s32[d] : 0u) | ((uint64_t)(d + 1 < n_dw ? s32[d + 1] : 0u) << 32);
                             f = (uint32_t)(two >> (p & 31u)) & mask;
                             if (PixelTraits<T>::is_signed) f = (uint32_t)((int32_t)(f << (32u - w)) >> (32u - w));
                         }
-                        fout[(uint64_t)blk * kBlock + k] = (T)f;
+                        dst[k] = (T)f;
                         p += w;
                     }
                 }
@@ -221,7 +234,7 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+    hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status);
     prof.mark(st);
     return hipGetLastError();

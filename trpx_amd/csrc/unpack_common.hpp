@@ -56,6 +56,76 @@ __device__ __forceinline__ void unpack_payload_w(const uint32_t* __restrict__ im
     }
 }
 
+// ---- register-resident variant (decode_frame.hip) ------------------------------------------------------------------
+// The lane's stream dwords are already in registers (`raw`, loaded straight from L2 with dwordx4 loads starting at the
+// dword that holds the block's first payload bit; s = that bit's position in raw[0]).  Extracts the 12 W-bit fields
+// with static shifts (v_bfe_u32 / v_bfe_i32), packs them to the pixel type and stores the block: no LDS, no merge of
+// the specialised bodies' results.
+template <typename T> struct RawQuads { static constexpr int n = PixelTraits<T>::bits == 32 ? 4 : (PixelTraits<T>::bits == 16 ? 2 : 1); };
+
+template <typename T, int W>
+__device__ __forceinline__ void unpack_store_w(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, T* __restrict__ dst) {
+    constexpr int bits = PixelTraits<T>::bits;
+    constexpr int NBITS = kBlock * W;
+    constexpr int ND = (NBITS + 31) / 32;
+    static_assert(ND + 1 <= 4 * RawQuads<T>::n, "field string must fit the loaded quads");
+    uint32_t x[ND ? ND : 1];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) x[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], s);   // string aligned to bit 0
+    uint32_t f[kBlock];
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k) {
+        if constexpr (W == 0) f[k] = 0u;
+        else {
+            const int bit = k * W;
+            uint32_t y = x[bit >> 5] >> (bit & 31);
+            if ((bit & 31) + W > 32) y |= x[(bit >> 5) + 1] << (32 - (bit & 31));
+            if (PixelTraits<T>::is_signed) f[k] = (uint32_t)((int32_t)(y << (32 - W)) >> (32 - W));   // sign-extend (:784-789)
+            else f[k] = W >= 32 ? y : y & ((1u << (W & 31)) - 1u);
+        }
+    }
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    if constexpr (bits == 32) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u4 o = {f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+            __builtin_nontemporal_store(o, reinterpret_cast<u4*>(dst) + i);
+        }
+    } else if constexpr (bits == 16) {                                               // v_perm_b32: {hi.lo16, lo.lo16}
+        uint32_t o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = __builtin_amdgcn_perm(f[2 * i + 1], f[2 * i], 0x05040100u);
+        u4 a = {o[0], o[1], o[2], o[3]};
+        u2 c = {o[4], o[5]};
+        __builtin_nontemporal_store(a, reinterpret_cast<u4*>(dst));                  // 24 bytes: one 16-byte + one 8-byte store
+        __builtin_nontemporal_store(c, reinterpret_cast<u2*>(dst) + 2);
+    } else {
+        uint32_t o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t lo = __builtin_amdgcn_perm(f[4 * i + 1], f[4 * i], 0x0c0c0400u);       // {0, 0, b.byte0, a.byte0}
+            const uint32_t hi = __builtin_amdgcn_perm(f[4 * i + 3], f[4 * i + 2], 0x0c0c0400u);
+            o[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        u2 a = {o[0], o[1]};
+        __builtin_nontemporal_store(a, reinterpret_cast<u2*>(dst));   // 12 bytes (4-byte aligned: block = 12 bytes)
+        __builtin_nontemporal_store(o[2], reinterpret_cast<uint32_t*>(dst) + 2);
+    }
+}
+
+template <typename T, int LO, int HI>
+struct UnpackStoreDispatch {
+    static __device__ __forceinline__ void run(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t w0, T* dst) {
+        if constexpr (LO == HI) unpack_store_w<T, LO>(raw, s, dst);
+        else {
+            constexpr int MID = (LO + HI) / 2;
+            if (w0 <= (uint32_t)MID) UnpackStoreDispatch<T, LO, MID>::run(raw, s, w0, dst);
+            else UnpackStoreDispatch<T, MID + 1, HI>::run(raw, s, w0, dst);
+        }
+    }
+};
+
 template <typename T, int LO, int HI>
 struct UnpackDispatch {
     static __device__ __forceinline__ void run(const uint32_t* image, uint32_t q, uint32_t w0, uint32_t (&u)[kBlock]) {
