@@ -128,13 +128,23 @@ def main():
                L.trpx_decode_workspace_bytes(_lib.U16, N_VALUES, frames, 12)))
     torch.cuda.synchronize()
 
+    # The per-frame size gather (RCCL over xGMI -> global byte offset of every frame) depends only on the encode and
+    # nothing in the decode depends on it: it runs on its own stream next to the decode and is joined at the step's end.
+    gather = sharded.SizeGather(frames, dev) if use_dist else None
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+
     def step():
         enc = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
-        if use_dist:    # per-frame size gather over xGMI -> global byte offsets of every frame
-            sharded.gather_global_offsets(offs, st_e[1:2], counts=[frames] * world, force=True)
+        if use_dist:
+            cur = torch.cuda.current_stream()
+            comm_stream.wait_stream(cur)
+            with torch.cuda.stream(comm_stream):
+                gather(offs, st_e[1:2])
         # decode straight from the device-resident stack (bounded by its worst-case capacity; the
         # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
         codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+        if use_dist:
+            torch.cuda.current_stream().wait_stream(comm_stream)
         return enc
 
     def barrier():

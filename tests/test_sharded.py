@@ -35,6 +35,11 @@ def _worker(rank, world, port, total_frames, q):
     counts = [sharded.frame_range(total_frames, r, world)[1] - sharded.frame_range(total_frames, r, world)[0] for r in range(world)]
     goffs2, base2, gpb2 = sharded.gather_global_offsets(local_offsets, torch.tensor([pb]), counts=counts)
     assert torch.equal(goffs, goffs2) and int(base) == int(base2) and int(gpb) == int(gpb2)
+    if total_frames % world == 0:                           # equal shards: the preallocated gather bench.py overlaps with decode
+        sg = sharded.SizeGather(hi - lo, "cpu")
+        for _ in range(2):                                   # buffers are reused call after call
+            goffs3, base3, gpb3 = sg(local_offsets, torch.tensor([pb], dtype=torch.int32))
+            assert torch.equal(goffs, goffs3) and int(base) == int(base3) and int(gpb) == int(gpb3)
     q.put((rank, goffs.numpy().copy(), int(base), int(gpb), data.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
@@ -61,6 +66,21 @@ def test_two_rank_size_gather_matches_single_process_stack():
         assert gpb == pb
         assembled[base:base + len(data)] = data             # each rank writes its shard at its global offset
     assert bytes(assembled) == want.tobytes()
+
+
+def test_two_rank_equal_shards_preallocated_gather():
+    world, total_frames = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == world
 
 
 def test_frame_range_partitions_exactly():

@@ -53,3 +53,29 @@ def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.
     my_base = global_offsets[sum(counts_host[:rank])]
     pb = gathered[:, fmax].max() if local_prolix_bits is not None else None
     return global_offsets, my_base, pb
+
+
+class SizeGather:
+    """The same exchange for a fixed, equal shard size, with every buffer allocated once: five small launches and one
+    collective per call, meant to run on its own stream next to the decode (which does not need the global offsets)."""
+
+    def __init__(self, frames_per_rank: int, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.f = int(frames_per_rank)
+        self.padded = torch.zeros(self.f + 1, dtype=torch.int64, device=device)
+        self.gathered = torch.empty(self.world * (self.f + 1), dtype=torch.int64, device=device)
+        self.global_offsets = torch.zeros(self.world * self.f + 1, dtype=torch.int64, device=device)
+
+    def __call__(self, local_offsets: torch.Tensor, local_prolix_bits: torch.Tensor):
+        """Returns (global_offsets, my_base, prolix_bits) like gather_global_offsets (views of internal buffers)."""
+        torch.sub(local_offsets[1:], local_offsets[:-1], out=self.padded[: self.f])
+        self.padded[self.f:].copy_(local_prolix_bits.reshape(-1)[:1])
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(self.gathered, self.padded, group=self.group)
+        else:
+            self.gathered.copy_(self.padded)
+        g = self.gathered.view(self.world, self.f + 1)
+        torch.cumsum(g[:, : self.f].reshape(-1), 0, out=self.global_offsets[1:])
+        return self.global_offsets, self.global_offsets[self.rank * self.f], g[:, self.f].max()
