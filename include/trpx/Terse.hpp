@@ -130,6 +130,19 @@ public:
         if constexpr (!std::is_pointer_v<Iterator>) std::copy(tmp.begin(), tmp.end(), begin);
     }
 
+    /// Unpacks EVERY frame into `out` (number_of_frames() x size() values) in one device call -- what src/prolix.cpp's
+    /// per-frame loop (:69-92) amounts to.
+    template <typename V>
+    void prolix_all(V* out) {
+        if (d_signed && std::is_unsigned_v<V>)
+            throw std::invalid_argument("signed data cannot be decompressed into unsigned data");
+        if (d_frame_sizes.empty()) return;
+        std::vector<std::uint64_t> offs(d_frame_sizes.size() + 1, 0);
+        for (std::size_t f = 0; f < d_frame_sizes.size(); ++f) offs[f + 1] = offs[f] + d_frame_sizes[f];
+        detail::check(trpx_decode_host(d_signed, detail::out_dtype_of<V>(), d_terse_data.data(), d_terse_data.size(), offs.data(),
+                                       d_size, d_frame_sizes.size(), d_block, out, -1), "Terse::prolix_all");
+    }
+
     std::size_t size() const { return d_size; }                                   // Terse.hpp:396
     std::size_t number_of_frames() const { return d_frame_sizes.size(); }         // :403
     std::vector<std::size_t> const& dim() const { return d_dim; }                 // :410

@@ -1,0 +1,111 @@
+"""Rows f2 / f3: the GPU-backed `terse` / `prolix` tools and the minimal grey TIFF reader / writer.
+
+Fixtures in tests/golden/cli (made by tests/golden/make_cli_golden.py with the REFERENCE tools, where /root/reference
+exists): small TIFF stacks, the .trpx the reference `terse` makes of each, and the TIFF `prolix` must write
+(`*.expect.tif`; index.json records for which of them the reference `prolix` wrote exactly these bytes -- all but the
+3-frame stack, where the reference mislocates frames >= 2, defects D1/D2).
+"""
+import json
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "tests", "golden", "cli")
+INDEX = json.load(open(os.path.join(CLI, "index.json")))
+
+
+def _parse_tiff(path):
+    """Independent little/big-endian parser of the reference writer's layout -> [n, h, w] array."""
+    b = open(path, "rb").read()
+    e = "<" if b[:2] == b"II" else ">"
+    ifd = struct.unpack_from(e + "I", b, 4)[0]
+    frames = []
+    while ifd:
+        n = struct.unpack_from(e + "H", b, ifd)[0]
+        tags = {}
+        for i in range(n):
+            tag, typ, cnt = struct.unpack_from(e + "HHI", b, ifd + 2 + 12 * i)
+            tags[tag] = struct.unpack_from(e + ("H" if typ == 3 else "I"), b, ifd + 2 + 12 * i + 8)[0]
+        kind = {1: "u", 2: "i", 3: "f"}[tags.get(0x153, 1)]
+        dt = np.dtype(f"{e}{kind}{tags[0x102] // 8}")
+        w, h = tags[0x100], tags[0x101]
+        frames.append(np.frombuffer(b, dt, w * h, tags[0x111]).reshape(h, w))
+        ifd = struct.unpack_from(e + "I", b, ifd + 2 + 12 * n)[0]
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_tiff_reader_writer_match_reference_layout(name, tmp_path):
+    """CPU: Grey_tif.hpp reads every fixture (little and big endian) and re-writes it, as `prolix` would, byte for byte
+    like the reference writer."""
+    exe = os.path.join(ROOT, "tests", "cpp", "tiff_roundtrip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "tiff_roundtrip"])
+    info = INDEX[name]
+    out = tmp_path / "out.tif"
+    bits = "16" if np.dtype(info["dtype"]).itemsize <= 2 else "32"
+    r = subprocess.run([exe, os.path.join(CLI, name + ".tif"), str(out), bits], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n, w, h, bpp, sgn, integral = (int(x) for x in r.stdout.split())
+    assert [n, h, w] == info["shape"] and bpp == np.dtype(info["dtype"]).itemsize
+    assert bool(sgn) == (np.dtype(info["dtype"]).kind == "i") and integral == 1
+    assert out.read_bytes() == open(os.path.join(CLI, info["expect_tif"]), "rb").read()
+    want = _parse_tiff(os.path.join(CLI, name + ".tif"))
+    assert (_parse_tiff(str(out)).astype(np.int64) == want.astype(np.int64)).all()
+    if info["reference_prolix_matches"] is not None and name != "u16_stack3_35x20":
+        assert info["reference_prolix_matches"]            # the expected files ARE what the reference writer produced
+
+
+def test_tiff_reader_rejects_corrupt_files(tmp_path):
+    exe = os.path.join(ROOT, "tests", "cpp", "tiff_roundtrip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "tiff_roundtrip"])
+    good = open(os.path.join(CLI, "i16_single_17x9.tif"), "rb").read()
+    for bad in (good[:40], b"XX" + good[2:], good[:4] + struct.pack("<I", len(good) + 100) + good[8:]):
+        p = tmp_path / "bad.tif"
+        p.write_bytes(bad)
+        r = subprocess.run([exe, str(p), str(tmp_path / "o.tif")], capture_output=True, text=True)
+        assert r.returncode == 1 and "error" in r.stderr     # the reference reads out of bounds instead
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_terse_cli_writes_the_reference_trpx(name, tmp_path):
+    """GPU: `terse file.tif` -> file.trpx, byte-identical (header text and payload) to the reference tool's output."""
+    exe = os.path.join(ROOT, "trpx_amd", "bin", "terse")
+    assert os.path.exists(exe), "build the tools first (__graft_entry__.build / make -C trpx_amd/cli)"
+    work = tmp_path / (name + ".tif")
+    shutil.copy(os.path.join(CLI, name + ".tif"), work)
+    junk = tmp_path / "notes.txt"
+    junk.write_text("not a tiff")                            # extension filter (terse.cpp:44-47)
+    r = subprocess.run([exe, "-verbose", str(work), str(junk)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Terse compressed: 1 files" in r.stdout and "Compression rate:" in r.stdout
+    assert work.exists()                                     # kept (the reference deletes it; -delete does that here)
+    assert (tmp_path / (name + ".trpx")).read_bytes() == open(os.path.join(CLI, name + ".trpx"), "rb").read()
+    r = subprocess.run([exe, "-delete", str(work)], capture_output=True, text=True)
+    assert r.returncode == 0 and not work.exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_prolix_cli_expands_the_reference_trpx(name, tmp_path):
+    """GPU: `prolix file.trpx` (a file written by the REFERENCE `terse`) -> file.tif with the expected bytes; for 32-bit
+    stacks and for stacks of >= 3 frames this is what the reference intends but does not do (D5, D1/D2)."""
+    exe = os.path.join(ROOT, "trpx_amd", "bin", "prolix")
+    assert os.path.exists(exe)
+    work = tmp_path / (name + ".trpx")
+    shutil.copy(os.path.join(CLI, name + ".trpx"), work)
+    r = subprocess.run([exe, "-verbose", str(work)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Prolix expanded : 1 files" in r.stdout
+    info = INDEX[name]
+    got = (tmp_path / (name + ".tif")).read_bytes()
+    assert got == open(os.path.join(CLI, info["expect_tif"]), "rb").read()
+    want = _parse_tiff(os.path.join(CLI, name + ".tif"))
+    assert (_parse_tiff(str(tmp_path / (name + ".tif"))).astype(np.int64) == want.astype(np.int64)).all()
