@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     {
                         uint32_t stride = 1u + kBlock * w_prev;
                         int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
+                        uint32_t wide = 0;                                // widest explicit block of these steps (checked once, after them)
                         while (b + 64u <= fast_end && (int32_t)pos < pos_max) {
                             const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;
                             const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
@@ -103,23 +104,23 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                             const uint64_t stop = ~__ballot((bits & 1u) != 0u);                           // Terse.hpp:361
                             const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
                             const uint32_t pick = first & 63u;
-                            const uint32_t e_w = first < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)wk, pick) : w_prev;
-                            const uint32_t adv = first < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)advk, pick) : 0u;
-                            if (e_w > kMaxW) { bad = true; break; }
-                            const uint32_t n_done = first < 64u ? first + 1u : 64u, rel = b - s * kStepBlocks;
+                            const uint32_t e_wx = (uint32_t)__builtin_amdgcn_readlane((int)wk, pick);
+                            const uint32_t advx = (uint32_t)__builtin_amdgcn_readlane((int)advk, pick);
+                            const bool run = first >= 64u;                                              // all 64 repeat w_prev
+                            const uint32_t e_w = run ? w_prev : e_wx, adv = run ? 0u : advx;
+                            wide = e_w > wide ? e_w : wide;
+                            const uint32_t n_done = run ? 64u : first + 1u, rel = b - s * kStepBlocks;
                             if (lane < n_done) {
                                 s_w[buf][1 + rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
                                 if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + lane * stride;
                             }
-                            pos += first * stride + adv;
+                            pos += first * stride + adv;                                                // (bounded by pos_max: inside the window)
                             b += n_done;
-                            if (e_w != w_prev) {
-                                w_prev = e_w;
-                                stride = 1u + kBlock * e_w;
-                                pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;
-                            }
-                            if (pos > limit + 64u * 400u) { bad = true; break; }      // ran away: corrupt stream
+                            w_prev = e_w;
+                            stride = 1u + kBlock * e_w;
+                            pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;
                         }
+                        if (wide > kMaxW) bad = true;                     // a corrupt header: at worst the steps above wrote bogus widths to LDS
                         if (bad || b >= end_b) break;
                     }
                     const uint32_t stride = 1u + kBlock * w_prev;
