@@ -61,6 +61,42 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
     uint64_t st_t0 = __builtin_amdgcn_s_memtime(), st_refill = 0; uint32_t st_steps = 0, st_refills = 0;
 #endif
     while (b < n_blocks) {
+        // ---- fast steps (see k_decode_frames): 64 real candidates, none of them the frame's last block, all inside the
+        // LDS window; every lane decodes "its" explicit header in parallel, the step itself is branch-free ----------------
+        {
+            uint32_t stride = 1u + kBlock * w_prev;
+            int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;
+            uint32_t wide = 0;
+            while (b + 64u < n_blocks && (int32_t)pos < pos_max) {
+#ifdef TRPX_WALK_STATS
+                ++st_steps;
+#endif
+                const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;
+                const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
+                const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
+                const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
+                const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;
+                const uint64_t stop = ~__ballot((bits & 1u) != 0u);
+                const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                const uint32_t pick = first & 63u;
+                const uint32_t e_wx = (uint32_t)__builtin_amdgcn_readlane((int)wk, pick);
+                const uint32_t advx = (uint32_t)__builtin_amdgcn_readlane((int)advk, pick);
+                const bool run = first >= 64u;
+                const uint32_t e_w = run ? w_prev : e_wx, adv = run ? 0u : advx;
+                wide = e_w > wide ? e_w : wide;
+                const uint32_t n_done = run ? 64u : first + 1u;
+                if (lane < n_done) {
+                    wf[b + lane] = (uint8_t)(lane < first ? w_prev : e_w);
+                    if (((b + lane) & (kTileBlocks - 1)) == 0) tf[(b + lane) / kTileBlocks] = pos + lane * stride;
+                }
+                pos += first * stride + adv;
+                b += n_done;
+                w_prev = e_w;
+                stride = 1u + kBlock * e_w;
+                pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;
+            }
+            if (wide > max_w) { bad = true; break; }
+        }
 #ifdef TRPX_WALK_STATS
         ++st_steps;
 #endif
