@@ -6,10 +6,10 @@
 //   wave 0 ("walker")    walks the frame's header chain (Terse.hpp:360-372) exactly like k_walk_lds --
 //                        64 candidate blocks per step, stream staged through a private LDS window --
 //                        but deposits width[b] and the 64-block group offsets in LDS instead of HBM.
-//   waves 1-3            one super-step (384 blocks = 6 groups) behind the walker: each wave takes two
-//                        groups, fetches the group's stream bytes (L2-hot: the walker has just read them),
-//                        extracts the 12 fields of every block with width-specialised code and stores
-//                        the pixels (24/48 bytes per lane, non-temporal).
+//   waves 1-3            one super-step (768 blocks = 12 groups of 64) behind the walker: each wave takes four
+//                        groups; every lane loads the stream dwords of its own block straight from L2 (the
+//                        walker has just pulled them through), extracts the 12 fields with width-specialised
+//                        code on registers and stores the pixels (24/48 bytes per lane, non-temporal).
 //   one barrier per super-step; width buffers are double buffered.
 //
 // The walk is the critical path (serial by construction of the format); the extraction hides under it.
@@ -33,11 +33,8 @@ constexpr int kFrameWaves = TRPX_FRAME_WAVES;           // waves per workgroup: 
 constexpr int kFrameThreads = kFrameWaves * kWave;
 constexpr int kGroupsPerWave = TRPX_FRAME_GPW;          // 64-block groups per unpack wave and super-step
 constexpr int kStepGroups = (kFrameWaves - 1) * kGroupsPerWave;   // 64-block groups per super-step
-constexpr int kStepBlocks = kStepGroups * kWave;       // 384
+constexpr int kStepBlocks = kStepGroups * kWave;       // 768
 constexpr int kFrameChunkDw = 2048;                    // walker's stream window: 8 KB
-
-template <typename T>
-constexpr int group_image_dwords() { return (kWave * max_block_bits<T>() + 31) / 32 + 12; }
 
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,

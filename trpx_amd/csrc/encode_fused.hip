@@ -4,18 +4,20 @@
 // pack primitives (Bit_range::append_range :700-730, operator|= :628-649, Bit::set :490).
 //
 // Work decomposition
-//   tile      = 1536 consecutive codec blocks (18 432 values; 768 for 32-bit pixels) of ONE frame, one
-//               256-thread workgroup.
-//   sub-tile  = 256 blocks; lane `tid` owns block (r*256 + tid) of sub-tile r = 0..5, so every
+//   tile      = 1024 consecutive codec blocks (12 288 values; 768 blocks for 32-bit pixels) of ONE frame, one
+//               256-thread workgroup; grid = (tiles per frame, frames), x fastest = dispatch in tile order.
+//   sub-tile  = 256 blocks; lane `tid` owns block (r*256 + tid) of sub-tile r = 0..3, so every
 //               wave-level load covers 1536 contiguous bytes (u16).
 //   The serial bit cursor of the reference (Terse.hpp:504) becomes three prefix sums:
-//     lanes -> wavefront DPP scan, wavefronts/sub-tiles -> LDS, tiles -> decoupled look-back
-//     through 8-byte descriptors in HBM (agent-scope relaxed atomics, the data is the flag):
-//       tile chain  (inside a frame)   : bits  -> exclusive bit offset of the tile in its frame
-//       frame chain (across the stack) : bytes -> S_f = 1 + bits/8 (Terse.hpp:547) -> frame base
-//   Packing: every lane serialises its block with code specialised on the block's width W (all
-//   shifts static), ORs it into the workgroup's LDS staging image at its scanned bit offset; the
-//   tile-relative image is flushed to HBM in whole dwords (coalesced) through one funnel shift.  A dword
+//     lanes -> wavefront DPP scan, wavefronts/sub-tiles -> LDS, tiles and frames -> 8-byte words in HBM
+//     (agent-scope relaxed atomics, the data is the flag):
+//       tile chain  (inside a frame)   : decoupled look-back over the frame's tile descriptors (bits)
+//       frame chain (across the stack) : every tile ADDS its bits to its frame's accumulator; only the frame's first
+//                                        tile walks the chain of complete frames (S_f = 1 + bits/8, Terse.hpp:547)
+//                                        and hands the frame's base to its siblings through the frame's own line
+//   Packing: every lane serialises its block -- header and payload as one bit string -- with code specialised
+//   on the block's width W (all shifts static), ORs it into the workgroup's LDS staging image at its scanned
+//   bit offset; the tile-relative image is flushed to HBM in 16-byte stores through one funnel shift.  A dword
 //   shared by two tiles is stored by k_stitch from the bits both sides deposit in an exchange word, so
 //   the output needs no pre-zeroing and nothing at a tile's end waits for another tile.
 //
