@@ -34,7 +34,10 @@ constexpr int kFrameThreads = kFrameWaves * kWave;
 constexpr int kGroupsPerWave = TRPX_FRAME_GPW;          // 64-block groups per unpack wave and super-step
 constexpr int kStepGroups = (kFrameWaves - 1) * kGroupsPerWave;   // 64-block groups per super-step
 constexpr int kStepBlocks = kStepGroups * kWave;       // 768
-constexpr int kFrameChunkDw = 2048;                    // walker's stream window: 8 KB
+#ifndef TRPX_FRAME_CHUNK_DW
+#define TRPX_FRAME_CHUNK_DW 4096
+#endif
+constexpr int kFrameChunkDw = TRPX_FRAME_CHUNK_DW;     // walker's stream window: 16 KB (1024 / 2048 / 4096 dwords: 0.333 / 0.326 / 0.318 ms)
 
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
