@@ -447,3 +447,67 @@ def test_converting_decode_cross_type_and_float(gpu, oracle):
     assert (t.prolix(np.empty(4000, np.int32)) == px.astype(np.int32)).all()
     assert (t.prolix(np.empty(4000, np.float64)) == px.astype(np.float64)).all()
     assert (t.prolix(np.empty(4000, np.uint8)) == np.minimum(px, 255).astype(np.uint8)).all()
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.int32, np.uint8])
+def test_encoder_chains_across_many_tiles_and_frames(gpu, oracle, dtype):
+    """Stresses the single-pass encoder's two chains (encode_fused.hip): one-tile frames in their hundreds (the frame
+    chain beyond one 64-frame look-back window, first tile == last tile), frames of a few tiles with a partial last
+    tile, and frames of more than 64 tiles (tile look-back beyond one window); widths vary from block to block so
+    that tile boundaries fall on arbitrary bits.  Vector-aligned sizes only (n % 4 == 0) -- the fused path."""
+    rng = np.random.RandomState(7)
+    dt = np.dtype(dtype)
+    tile_values = (1024 if dt.itemsize <= 2 else 768) * 12
+    top = 8 * dt.itemsize - (1 if dt.kind == "i" else 0)
+    for frames, n in ((700, 1000), (200, 4), (130, 2 * tile_values + 40), (3, 70 * tile_values + 8), (67, tile_values)):
+        # per-block magnitude: mostly narrow, some wide, so that widths change almost every block
+        nblk = (n + 11) // 12
+        hi = rng.choice([0, 1, 2, 3, 5, min(9, top), top], size=(frames, nblk), p=[0.1, 0.2, 0.3, 0.2, 0.1, 0.07, 0.03])
+        mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+        if dt.kind == "i":
+            mag = np.clip(mag * rng.choice([-1, 1], size=mag.shape), np.iinfo(dt).min, np.iinfo(dt).max)
+        px = mag.astype(dt)
+        want, sizes, pb = oracle.encode_stack(px)
+        got, offs, gpb = _host_encode(px)
+        assert (np.diff(offs).astype(np.uint64) == sizes).all(), (dtype, frames, n)
+        assert got.size == want.size and (got == want).all(), (dtype, frames, n)
+        assert gpb == pb
+        assert (_host_decode(got, offs, n, frames, dt) == px).all(), (dtype, frames, n)
+        assert (_host_decode(got, None, n, frames, dt) == px).all(), (dtype, frames, n)   # frames located by the device walk
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_two_pass_pipeline_and_basic_decoder_all_dtypes(gpu, oracle, dtype):
+    """The fallback pipelines (two-pass encode: encode.hip; basic walk + unpack: decode.hip) against the oracle for every
+    pixel type, with widths that change from block to block, three times over (a byte-packing code path of the basic
+    8-bit unpack kernel once gave run-to-run different pixels)."""
+    import torch
+    from trpx_amd import codec, _lib
+    rng = np.random.RandomState(5)
+    dt = np.dtype(dtype)
+    top = 8 * dt.itemsize - (1 if dt.kind == "i" else 0)
+    frames, n = 150, 1000
+    nblk = (n + 11) // 12
+    hi = rng.choice([0, 1, 2, 3, 5, min(9, top), top], size=(frames, nblk), p=[0.1, 0.2, 0.3, 0.2, 0.1, 0.07, 0.03])
+    mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+    if dt.kind == "i":
+        mag = np.clip(mag * rng.choice([-1, 1], size=mag.shape), np.iinfo(dt).min, np.iinfo(dt).max)
+    px = mag.astype(dt)
+    want, sizes, pb = oracle.encode_stack(px)
+    dpx = torch.from_numpy(px.view(np.int8 if dt.itemsize == 1 else np.int16 if dt.itemsize == 2 else np.int32)).to(gpu).view(
+        {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
+         4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize])
+    _lib.lib().trpx_set_encode_path(1)
+    try:
+        enc = codec.encode(dpx)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().trpx_set_encode_path(0)
+    enc.check()
+    assert enc.stack().cpu().numpy().tobytes() == want.tobytes()
+    assert enc.prolix_bits() == pb
+    for _ in range(3):
+        back, st = codec.decode(enc.stack(), None, n, frames, dt)        # no offsets: serial walk + basic unpack
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0
+        assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all()

@@ -175,9 +175,12 @@ __global__ __launch_bounds__(kThreads) void k_unpack(const uint8_t* __restrict__
 
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     const uint64_t pos = tile_off[tile] + excl + hl;        // first payload bit, relative to the frame
-    T vals[kBlock];
+    // one 32-bit register per value: with T vals[] the compiler packs four 8-bit values per register and updates single
+    // bytes under the refill / tail predicates -- that build produced run-to-run different pixels for 8-bit types
+    // (tests/test_gpu_parity.py::test_encoder_chains_across_many_tiles_and_frames found it)
+    uint32_t vals[kBlock];
 #pragma unroll
-    for (int k = 0; k < kBlock; ++k) vals[k] = (T)0;        // w == 0 -> zeros (Terse.hpp:373-374)
+    for (int k = 0; k < kBlock; ++k) vals[k] = 0u;           // w == 0 -> zeros (Terse.hpp:373-374)
 
     if (w) {
         if (pos + (uint64_t)nb * w > 8 * (fe - fo) || w > (uint32_t)PixelTraits<T>::bits) {
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack(const uint8_t* __restrict__
                     avail -= w;
                     if (PixelTraits<T>::is_signed)          // sign-extend from bit w-1 (:784-789)
                         u = (uint32_t)((int32_t)(u << (32u - w)) >> (32u - w));
-                    vals[k] = (T)u;
+                    vals[k] = u;
                 }
             }
         }
@@ -216,16 +219,16 @@ __global__ __launch_bounds__(kThreads) void k_unpack(const uint8_t* __restrict__
             QuadOut<T>* q = reinterpret_cast<QuadOut<T>*>(dst);
             QuadOut<T> a, c, d;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a.x[k] = vals[k]; c.x[k] = vals[4 + k]; d.x[k] = vals[8 + k]; }
+            for (int k = 0; k < 4; ++k) { a.x[k] = (T)vals[k]; c.x[k] = (T)vals[4 + k]; d.x[k] = (T)vals[8 + k]; }
             q[0] = a; q[1] = c; q[2] = d;
         } else {
 #pragma unroll
-            for (int k = 0; k < kBlock; ++k) dst[k] = vals[k];
+            for (int k = 0; k < kBlock; ++k) dst[k] = (T)vals[k];
         }
     } else {
 #pragma unroll
         for (int k = 0; k < kBlock; ++k)
-            if (k < nb) dst[k] = vals[k];
+            if (k < nb) dst[k] = (T)vals[k];
     }
 }
 
