@@ -511,3 +511,38 @@ def test_two_pass_pipeline_and_basic_decoder_all_dtypes(gpu, oracle, dtype):
         torch.cuda.synchronize()
         assert int(st[0]) == 0
         assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_every_decode_path_every_dtype_block_to_block_width_changes(gpu, oracle, dtype):
+    """One noisy stack per pixel type (the width changes with almost every block, including the type's full width),
+    encoded by the single-pass encoder with the decode index, then decoded along every route the library has:
+    per-frame decoder (>= 128 frames), tiled decoder (< 128 frames), walk-free indexed decoder, serial walk without
+    offsets -- three repetitions each (timing-dependent bugs show as run-to-run differences)."""
+    import torch
+    from trpx_amd import codec
+    rng = np.random.RandomState(99)
+    dt = np.dtype(dtype)
+    top = 8 * dt.itemsize - (1 if dt.kind == "i" else 0)
+    tdt = {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
+           4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
+    for frames, n in ((140, 3000), (6, 40000)):
+        nblk = (n + 11) // 12
+        hi = rng.choice([0, 1, 2, 3, 5, min(9, top), top], size=(frames, nblk), p=[0.1, 0.2, 0.3, 0.2, 0.1, 0.07, 0.03])
+        mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+        if dt.kind == "i":
+            mag = np.clip(mag * rng.choice([-1, 1], size=mag.shape), np.iinfo(dt).min, np.iinfo(dt).max)
+        px = mag.astype(dt)
+        want, sizes, pb = oracle.encode_stack(px)
+        dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
+        enc = codec.encode(dpx, index=True)
+        torch.cuda.synchronize()
+        enc.check()
+        assert enc.stack().cpu().numpy().tobytes() == want.tobytes(), (dtype, frames)
+        for rep in range(3):
+            for kind in ("offsets", "index", "walk"):
+                back, st = codec.decode(enc.stack(), None if kind == "walk" else enc.frame_offsets, n, frames, dt,
+                                        index=enc.index if kind == "index" else None)
+                torch.cuda.synchronize()
+                assert int(st[0]) == 0, (dtype, frames, kind)
+                assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, frames, kind, rep)
