@@ -156,8 +156,10 @@ public:
     std::vector<std::size_t> const& frame_sizes() const { return d_frame_sizes; }
     std::vector<std::uint8_t> const& data() const { return d_terse_data; }
 
-    /// XML-ish header + raw stack (Terse.hpp:454-474), byte-identical header text.
-    void write(std::ostream& ostream) const {
+    /// XML-ish header + raw stack (Terse.hpp:454-474), byte-identical header text.  frame_index = true adds the
+    /// frame_sizes attribute: the reference reader ignores it, this reader then needs no
+    /// device walk to locate the frames.
+    void write(std::ostream& ostream, bool frame_index = false) const {
         trpx_header h{};
         h.prolix_bits = d_prolix_bits;
         h.is_signed = d_signed;
@@ -167,9 +169,11 @@ public:
         h.number_of_frames = d_frame_sizes.size();
         h.n_dims = (unsigned)std::min<std::size_t>(d_dim.size(), 8);
         for (unsigned i = 0; i < h.n_dims; ++i) h.dims[i] = d_dim[i];
-        char buf[512];
-        const std::size_t n = trpx_header_format(&h, buf, sizeof buf);
-        ostream.write(buf, (std::streamsize)n);
+        std::vector<char> buf(512 + (frame_index ? 21 * d_frame_sizes.size() : 0));
+        std::vector<std::uint64_t> sizes(d_frame_sizes.begin(), d_frame_sizes.end());
+        const std::size_t n = frame_index ? trpx_header_format_indexed(&h, sizes.data(), sizes.size(), buf.data(), buf.size())
+                                          : trpx_header_format(&h, buf.data(), buf.size());
+        ostream.write(buf.data(), (std::streamsize)n);
         ostream.write(reinterpret_cast<const char*>(d_terse_data.data()), (std::streamsize)d_terse_data.size());
         ostream.flush();
     }
@@ -207,13 +211,19 @@ private:
 
     void f_read(std::ifstream& istream) {
         const std::streampos pos = istream.tellg();
-        char blob[4096];
-        istream.read(blob, sizeof blob);
-        const std::size_t got = (std::size_t)istream.gcount();
-        istream.clear();
+        std::vector<char> blob;
+        std::size_t got = 0, off = 0;
         trpx_header h;
-        std::size_t off = 0;
-        if (trpx_header_parse(blob, got, &h, &off) != TRPX_OK) throw std::invalid_argument("no valid <Terse .../> header");
+        for (std::size_t want = 4096;; want <<= 4) {                               // an indexed header can be long
+            blob.resize(want);
+            istream.clear();
+            istream.seekg(pos);
+            istream.read(blob.data(), (std::streamsize)want);
+            got = (std::size_t)istream.gcount();
+            istream.clear();
+            if (trpx_header_parse(blob.data(), got, &h, &off) == TRPX_OK) break;
+            if (got < want || want >= (std::size_t(1) << 28)) throw std::invalid_argument("no valid <Terse .../> header");
+        }
         d_prolix_bits = h.prolix_bits;
         d_signed = h.is_signed;
         d_block = h.block;
@@ -223,7 +233,14 @@ private:
         istream.seekg(pos + std::streamoff(off));
         istream.read(reinterpret_cast<char*>(d_terse_data.data()), (std::streamsize)d_terse_data.size());
         if ((std::size_t)istream.gcount() != d_terse_data.size()) throw std::runtime_error("truncated .trpx payload");
+        std::vector<std::uint64_t> sizes(h.number_of_frames ? h.number_of_frames : 1);
+        const std::size_t have = trpx_header_frame_sizes(blob.data(), got, sizes.data(), sizes.size());
+        std::uint64_t sum = 0;
+        bool positive = true;
+        for (std::size_t i = 0; i < have && i < sizes.size(); ++i) { sum += sizes[i]; positive = positive && sizes[i] > 0; }
         if (h.number_of_frames == 1) d_frame_sizes = {d_terse_data.size()};
+        else if (h.number_of_frames > 1 && have == h.number_of_frames && positive && sum == d_terse_data.size())
+            d_frame_sizes.assign(sizes.begin(), sizes.end());                      // row f1: the file carries its frame index
         else if (h.number_of_frames > 1) {
             std::vector<std::uint64_t> offs(h.number_of_frames + 1);
             const unsigned max_bits = h.prolix_bits <= 8 ? 8 : h.prolix_bits <= 16 ? 16 : 32;

@@ -214,6 +214,17 @@ size_t trpx_header_format(const trpx_header* h, char* buf, size_t buf_cap);
  * mandatory. */
 int trpx_header_parse(const char* data, size_t len, trpx_header* h, size_t* payload_offset);
 
+/* Frame index side-channel in the FILE.  The reference's file stores no frame sizes
+ * (Terse.hpp:454-474), so a reader has to walk every frame's header chain just to find the next frame
+ * (Terse.hpp:562-585).  trpx_header_format_indexed writes the same header with one more attribute,
+ *   frame_sizes="S_0 S_1 ... S_{F-1}"      (bytes per frame, their sum = memory_size),
+ * in front of number_of_frames.  The reference reader looks attributes up by name and ignores the others
+ * (XML_element.hpp:296-307), so such a file stays readable by the reference tools; trpx_header_frame_sizes returns
+ * the number of sizes found (0: no such attribute) and fills at most `capacity` of them.  Returns 0 / leaves buf
+ * untouched if buf_cap is too small (2000 frames need ~14 KB). */
+size_t trpx_header_format_indexed(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, char* buf, size_t buf_cap);
+size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,3 +109,78 @@ def test_prolix_cli_expands_the_reference_trpx(name, tmp_path):
     assert got == open(os.path.join(CLI, info["expect_tif"]), "rb").read()
     want = _parse_tiff(os.path.join(CLI, name + ".tif"))
     assert (_parse_tiff(str(tmp_path / (name + ".tif"))).astype(np.int64) == want.astype(np.int64)).all()
+
+
+def _indexed_trpx(name):
+    """The reference `terse`'s file of a fixture with the frame_sizes attribute added (row f1), built on the CPU:
+    frame sizes from the oracle, header text from the library's host-only formatter."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from trpx_amd import _lib
+    info = INDEX[name]
+    frames = _parse_tiff(os.path.join(CLI, name + ".tif"))
+    px = np.ascontiguousarray(frames.reshape(frames.shape[0], -1).astype(np.dtype(info["dtype"])))
+    stream, sizes, pb = O.encode_stack(px)
+    blob = open(os.path.join(CLI, name + ".trpx"), "rb").read()
+    h = _lib.trpx_header()
+    off = C.c_size_t(0)
+    assert _lib.lib().trpx_header_parse(blob, len(blob), C.byref(h), C.byref(off)) == _lib.OK
+    assert blob[off.value:] == stream.tobytes()              # the oracle agrees with the reference tool's payload
+    buf = C.create_string_buffer(4096)
+    s64 = np.asarray(sizes, np.uint64)
+    n = _lib.lib().trpx_header_format_indexed(C.byref(h), s64.ctypes.data, s64.size, buf, 4096)
+    assert n > 0 and b' frame_sizes="' in buf.raw[:n]
+    back = np.zeros(s64.size, np.uint64)
+    assert _lib.lib().trpx_header_frame_sizes(buf.raw[:n], n, back.ctypes.data, back.size) == s64.size and (back == s64).all()
+    assert _lib.lib().trpx_header_frame_sizes(blob, len(blob), back.ctypes.data, back.size) == 0   # plain header: none
+    return buf.raw[:n] + stream.tobytes()
+
+
+@pytest.mark.parametrize("name", ["u8_stack2_16x12", "u16_bigendian_24x24", "i16_single_17x9"])
+def test_reference_prolix_ignores_the_frame_index_attribute(name, tmp_path):
+    """CPU, only where the reference tools can be built (/root/reference): a .trpx file with the extra frame_sizes
+    attribute expands with the REFERENCE `prolix` to the same TIFF as the plain file (stacks of <= 2 frames: the
+    reference mislocates later frames either way, D1/D2)."""
+    indexed = _indexed_trpx(name)
+    ref = os.path.join(ROOT, "oracle", "_ref", "prolix_cli")
+    if not os.path.exists(ref):
+        if not os.path.isdir("/root/reference"):
+            pytest.skip("reference sources not available here")
+        subprocess.check_call(["g++", "-std=c++20", "-O2", "-w", "-I/root/reference/include", "/root/reference/src/prolix.cpp",
+                               "-o", ref])
+    work = tmp_path / (name + ".trpx")
+    work.write_bytes(indexed)
+    subprocess.check_call([ref, str(work)], stdout=subprocess.DEVNULL)
+    assert (tmp_path / (name + ".tif")).read_bytes() == open(os.path.join(CLI, INDEX[name]["expect_tif"]), "rb").read()
+
+
+@pytest.mark.gpu
+def test_indexed_files_round_trip_through_tools_and_classes(tmp_path):
+    """GPU: `terse -index` writes the attribute, `prolix` and both Terse classes read such files (and plain ones)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from trpx_amd import Terse
+    name = "u16_stack3_35x20"
+    work = tmp_path / (name + ".tif")
+    shutil.copy(os.path.join(CLI, name + ".tif"), work)
+    terse, prolix = (os.path.join(ROOT, "trpx_amd", "bin", x) for x in ("terse", "prolix"))
+    assert subprocess.run([terse, "-index", str(work)], capture_output=True).returncode == 0
+    made = (tmp_path / (name + ".trpx")).read_bytes()
+    assert made == _indexed_trpx(name)
+    want = _parse_tiff(os.path.join(CLI, name + ".tif"))
+    with open(tmp_path / (name + ".trpx"), "rb") as f:
+        t = Terse.read(f)
+    assert t.number_of_frames() == 3 and sum(t.frame_sizes()) == t.terse_size()
+    assert (t.prolix_stack(np.uint16).reshape(want.shape) == want).all()
+    import io
+    out = io.BytesIO()
+    t.write(out, frame_index=True)
+    assert out.getvalue() == made
+    out = io.BytesIO()
+    t.write(out)
+    assert out.getvalue() == open(os.path.join(CLI, name + ".trpx"), "rb").read()        # and the plain header again
+    os.remove(work)
+    assert subprocess.run([prolix, str(tmp_path / (name + ".trpx"))], capture_output=True).returncode == 0
+    assert work.read_bytes() == open(os.path.join(CLI, INDEX[name]["expect_tif"]), "rb").read()

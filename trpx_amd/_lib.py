@@ -56,6 +56,8 @@ SYMBOLS = {
     "trpx_synth_fill": (_I, [_I, _U64, _U64, _SZ, _SZ, _P, _P]),
     "trpx_header_format": (_SZ, [C.POINTER(trpx_header), C.c_char_p, _SZ]),
     "trpx_header_parse": (_I, [C.c_char_p, _SZ, C.POINTER(trpx_header), C.POINTER(_SZ)]),
+    "trpx_header_format_indexed": (_SZ, [C.POINTER(trpx_header), C.c_void_p, _SZ, C.c_char_p, _SZ]),
+    "trpx_header_frame_sizes": (_SZ, [C.c_char_p, _SZ, C.c_void_p, _SZ]),
 }
 
 _lib = None

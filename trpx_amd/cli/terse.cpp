@@ -1,6 +1,6 @@
 // terse -- compresses greyscale TIFF stacks to .trpx files on the MI355X.
 // Command line and behaviour of the reference tool (senikm/trpx src/terse.cpp:20-104, type dispatch :107-125):
-//   terse [-help] [-verbose] [-delete] [file ...]
+//   terse [-help] [-verbose] [-delete] [-index] [file ...]
 // every argument with a .tif / .tiff / .TIF / .TIFF extension is read, all images of its stack are pushed into ONE
 // Terse object (one device call for the whole stack) and written next to it as <name>.trpx; -verbose prints the
 // reference's report.  Differences: the input is kept unless -delete is given (the reference always deletes it,
@@ -30,17 +30,18 @@ static void compress_stack(trpx::Terse& out, trpx::Grey_tif const& tif) {
 }
 
 int main(int argc, char const* argv[]) {
-    bool help = false, verbose = false, del = false;
+    bool help = false, verbose = false, del = false, index = false;
     std::vector<fs::path> params;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-help") help = true;
         else if (a == "-verbose") verbose = true;
         else if (a == "-delete") del = true;
+        else if (a == "-index") index = true;
         else params.emplace_back(a);
     }
     if (help) {
-        std::cout << "terse [-help] [-verbose] [-delete] [file ...]\n"
+        std::cout << "terse [-help] [-verbose] [-delete] [-index] [file ...]\n"
                      "  compresses all files with .tiff or .tif extensions to terse files with .trpx extensions (on the GPU).\n"
                      "Examples:\n"
                      "   terse *                   // all tiff files in this directory are compressed to trpx files.\n"
@@ -48,7 +49,9 @@ int main(int argc, char const* argv[]) {
                      "\nkeywords:\n"
                      "  -help      print help\n"
                      "  -verbose   print compressed filenames, compute times and compression rate\n"
-                     "  -delete    delete each TIFF file after it has been compressed (the reference tool always does)\n";
+                     "  -delete    delete each TIFF file after it has been compressed (the reference tool always does)\n"
+                     "  -index     add the frame_sizes attribute to the header (ignored by the reference reader; lets prolix locate\n"
+                     "             the frames of a stack without walking them)\n";
         return 0;
     }
     std::chrono::duration<double> user_time(0), io_time(0);
@@ -96,7 +99,7 @@ int main(int argc, char const* argv[]) {
             trpx_name.replace_extension(".trpx");
             std::ofstream out(trpx_name, std::ios::binary);
             if (!out.is_open()) throw std::runtime_error("Failed to open trpx file for output.");
-            compressed.write(out);
+            compressed.write(out, index);
             out.close();
             if (del) {
                 std::cout << "Deleting original TIFF file: " << tif_name << std::endl;

@@ -12,8 +12,26 @@
 
 #include "../../include/trpx_hip.h"
 
+static std::string header_string(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes);
+
 extern "C" size_t trpx_header_format(const trpx_header* h, char* buf, size_t buf_cap) {
     if (!h || !buf) return 0;
+    const std::string s = header_string(h, nullptr, 0);
+    if (s.size() + 1 > buf_cap) return 0;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return s.size();
+}
+
+extern "C" size_t trpx_header_format_indexed(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, char* buf,
+                                             size_t buf_cap) {
+    if (!h || !buf || (!frame_sizes && n_sizes)) return 0;
+    const std::string s = header_string(h, frame_sizes, n_sizes);
+    if (s.size() + 1 > buf_cap) return 0;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return s.size();
+}
+
+static std::string header_string(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes) {
     std::string s = "<Terse prolix_bits=\"" + std::to_string(h->prolix_bits) + "\"";
     s += " signed=\"" + std::to_string(h->is_signed ? 1 : 0) + "\"";
     s += " block=\"" + std::to_string(h->block) + "\"";
@@ -27,10 +45,16 @@ extern "C" size_t trpx_header_format(const trpx_header* h, char* buf, size_t buf
         }
         s += "\"";
     }
+    if (n_sizes) {                                            // row f1: optional, ignored by the reference reader
+        s += " frame_sizes=\"";
+        for (size_t i = 0; i < n_sizes; ++i) {
+            if (i) s += " ";
+            s += std::to_string((unsigned long long)frame_sizes[i]);
+        }
+        s += "\"";
+    }
     s += " number_of_frames=\"" + std::to_string((unsigned long long)h->number_of_frames) + "\"/>";
-    if (s.size() + 1 > buf_cap) return 0;
-    memcpy(buf, s.c_str(), s.size() + 1);
-    return s.size();
+    return s;
 }
 
 static bool is_white(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
@@ -88,4 +112,48 @@ extern "C" int trpx_header_parse(const char* data, size_t len, trpx_header* h, s
     if (!(got_pb && got_sg && got_bl && got_ms && got_nv && got_nf)) return TRPX_ERR_CORRUPT;
     if (payload_offset) *payload_offset = q + 1;
     return TRPX_OK;
+}
+
+// The optional frame_sizes attribute (trpx_header_format_indexed): same scan as trpx_header_parse.
+extern "C" size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity) {
+    if (!data) return 0;
+    static const char tag[] = "<Terse";
+    const size_t tl = sizeof(tag) - 1;
+    size_t p = 0;
+    for (;; ++p) {
+        if (p + tl >= len) return 0;
+        if (data[p] == '<' && memcmp(data + p, tag, tl) == 0 && (is_white(data[p + tl]) || data[p + tl] == '/' || data[p + tl] == '>')) break;
+    }
+    size_t q = p + tl;
+    while (q < len && data[q] != '>') {
+        if (is_white(data[q]) || data[q] == '/') { ++q; continue; }
+        const size_t ns = q;
+        while (q < len && data[q] != '=' && data[q] != '>' && !is_white(data[q])) ++q;
+        const std::string name(data + ns, q - ns);
+        while (q < len && is_white(data[q])) ++q;
+        if (q >= len || data[q] != '=') return 0;
+        ++q;
+        while (q < len && is_white(data[q])) ++q;
+        if (q >= len) return 0;
+        const char quote = data[q++];
+        const size_t vs = q;
+        while (q < len && data[q] != quote) ++q;
+        if (q >= len) return 0;
+        if (name == "frame_sizes") {
+            const std::string val(data + vs, q - vs);
+            const char* t = val.c_str();
+            size_t n = 0;
+            for (;;) {
+                char* end = nullptr;
+                const unsigned long long v = strtoull(t, &end, 10);
+                if (end == t) break;
+                if (frame_sizes && n < capacity) frame_sizes[n] = v;
+                ++n;
+                t = end;
+            }
+            return n;
+        }
+        ++q;
+    }
+    return 0;
 }

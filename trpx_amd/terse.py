@@ -148,7 +148,9 @@ class Terse:
         return list(self._dim)
 
     # ---- stream-serialise surface (Terse.hpp:454-474, :279, :485-498) -----------------------
-    def header(self) -> bytes:
+    def header(self, frame_index: bool = False) -> bytes:
+        """Header text of ``write`` (Terse.hpp:454-470).  ``frame_index=True`` adds the ``frame_sizes`` attribute
+        (SURVEY.md section 8 row f1): ignored by the reference reader, lets ``read`` skip the device walk."""
         h = _lib.trpx_header()
         h.prolix_bits, h.is_signed, h.block = self._prolix_bits, int(self._signed), self._block
         h.memory_size, h.number_of_values = len(self._data), self._size
@@ -156,14 +158,19 @@ class Terse:
         h.n_dims = len(self._dim)
         for i, d in enumerate(self._dim[:8]):
             h.dims[i] = d
-        buf = C.create_string_buffer(512)
-        n = lib().trpx_header_format(C.byref(h), buf, 512)
+        cap = 512 + (21 * len(self._frame_sizes) if frame_index else 0)
+        buf = C.create_string_buffer(cap)
+        if frame_index:
+            sizes = np.asarray(self._frame_sizes, np.uint64)
+            n = lib().trpx_header_format_indexed(C.byref(h), sizes.ctypes.data, sizes.size, buf, cap)
+        else:
+            n = lib().trpx_header_format(C.byref(h), buf, cap)
         if n == 0:
             raise RuntimeError("header does not fit")
         return buf.raw[:n]
 
-    def write(self, ostream) -> None:
-        ostream.write(self.header())
+    def write(self, ostream, frame_index: bool = False) -> None:
+        ostream.write(self.header(frame_index))
         ostream.write(bytes(self._data))
         if hasattr(ostream, "flush"):
             ostream.flush()
@@ -173,10 +180,16 @@ class Terse:
         """``Terse(std::ifstream&)``: scan for the header, read the payload, leave the stream
         positioned on the byte after it (Terse.hpp:275-279)."""
         pos = istream.tell()
-        blob = istream.read(4096)
         h = _lib.trpx_header()
         off = C.c_size_t(0)
-        rc = lib().trpx_header_parse(blob, len(blob), C.byref(h), C.byref(off))
+        want = 4096
+        while True:                                          # an indexed header (frame_sizes) can be long: read more
+            istream.seek(pos)
+            blob = istream.read(want)
+            rc = lib().trpx_header_parse(blob, len(blob), C.byref(h), C.byref(off))
+            if rc == _lib.OK or len(blob) < want or want >= 1 << 28:
+                break
+            want <<= 4
         if rc != _lib.OK:
             raise ValueError("no valid <Terse .../> header found")   # the reference's stoul throws
         t = cls(block=h.block, device=device)
@@ -187,8 +200,12 @@ class Terse:
         if len(t._data) != h.memory_size:
             raise ValueError("truncated .trpx payload")
         n_frames = int(h.number_of_frames)
+        sizes = np.empty(max(n_frames, 1), np.uint64)
+        have = lib().trpx_header_frame_sizes(blob, len(blob), sizes.ctypes.data, sizes.size)
         if n_frames == 1:
             t._frame_sizes = [len(t._data)]
+        elif n_frames > 1 and have == n_frames and int(sizes.sum()) == len(t._data) and (sizes > 0).all():
+            t._frame_sizes = [int(x) for x in sizes]          # row f1: the file carries its own frame index
         elif n_frames > 1:
             # The file stores no frame index: locate the frames with the device's header walk.
             buf = np.frombuffer(t._data, np.uint8)
