@@ -176,7 +176,8 @@ template <> struct QuadVec<int16_t>  { typedef uint32_t type __attribute__((ext_
 template <> struct QuadVec<uint32_t> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 template <> struct QuadVec<int32_t>  { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 
-// A full, vector-aligned block (3 x 4 values).
+// A full, vector-aligned block (3 x 4 values).  (A software prefetch of a future tile -- one dword per 128-byte line of the
+// tile 768..6144 positions further on, issued after barrier #1 -- was measured: 0.32-0.39 ms instead of 0.31.)
 template <typename T>
 __device__ __forceinline__ void load_raw_nt(const T* __restrict__ p, uint32_t (&raw)[Raw<T>::dw]) {
     using V = typename QuadVec<T>::type;
