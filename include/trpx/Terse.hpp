@@ -153,6 +153,9 @@ public:
     bool is_signed() const { return d_signed; }                                   // :428
     unsigned bits_per_val() const { return d_prolix_bits; }                       // :435
     std::size_t terse_size() const { return d_terse_data.size(); }                // :444
+    /// True if the reference's ImageJ plugin accepts a file written from this object (ImageJ/TRPX_Reader.java:94-98:
+    /// unsigned data of at most 16 bits per value; the file must fit a Java byte array).
+    bool imagej_readable() const { return !d_signed && d_prolix_bits <= 16 && d_terse_data.size() < (std::size_t(1) << 31) - 4096; }
     std::vector<std::size_t> const& frame_sizes() const { return d_frame_sizes; }
     std::vector<std::uint8_t> const& data() const { return d_terse_data; }
 

@@ -86,6 +86,8 @@ def test_terse_cli_writes_the_reference_trpx(name, tmp_path):
     r = subprocess.run([exe, "-verbose", str(work), str(junk)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Terse compressed: 1 files" in r.stdout and "Compression rate:" in r.stdout
+    dtn = np.dtype(INDEX[name]["dtype"])                     # ImageJ/TRPX_Reader.java:94-98: unsigned, <= 16 bits only
+    assert ("ImageJ TRPX reader only opens" in r.stdout) == (dtn.kind == "i" or dtn.itemsize == 4)
     assert work.exists()                                     # kept (the reference deletes it; -delete does that here)
     assert (tmp_path / (name + ".trpx")).read_bytes() == open(os.path.join(CLI, name + ".trpx"), "rb").read()
     r = subprocess.run([exe, "-delete", str(work)], capture_output=True, text=True)

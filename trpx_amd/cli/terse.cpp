@@ -95,6 +95,9 @@ int main(int argc, char const* argv[]) {
             default: throw std::runtime_error("unsupported pixel type.");
             }
             total_trpx += (double)compressed.terse_size();
+            if (verbose && !compressed.imagej_readable())
+                std::cout << "Note: " << tif_name << " is " << (compressed.is_signed() ? "signed, " : "unsigned, ") << compressed.bits_per_val()
+                          << " bits per value: the ImageJ TRPX reader only opens unsigned data of at most 16 bits." << std::endl;
             fs::path trpx_name = tif_name;
             trpx_name.replace_extension(".trpx");
             std::ofstream out(trpx_name, std::ios::binary);

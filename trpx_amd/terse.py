@@ -134,6 +134,11 @@ class Terse:
     def terse_size(self) -> int:
         return len(self._data)
 
+    def imagej_readable(self) -> bool:
+        """True if the reference's ImageJ plugin accepts a file written from this object: it only reads unsigned data
+        of at most 16 bits per value (ImageJ/TRPX_Reader.java:94-98) and the whole file must fit a Java byte array."""
+        return (not self._signed) and self._prolix_bits <= 16 and len(self._data) < (1 << 31) - 4096
+
     def frame_sizes(self) -> list[int]:
         return list(self._frame_sizes)
 
