@@ -12,7 +12,8 @@
 //     its Release build, CMakeLists.txt:13); device/runtime failures throw std::runtime_error;
 //   * push_back(Iterator, size, n_frames) encodes a whole stack in one GPU call (the reference's
 //     per-frame push_back is O(F^2), defect D6);
-//   * pixel types: u8/i8/u16/i16/u32/i32 (src/terse.cpp:113-118); 64-bit pixels are rejected.
+//   * pixel types: u8/i8/u16/i16/u32/i32 (src/terse.cpp:113-118); 64-bit integers are accepted when every value fits
+//     32 bits (the stream is then the same), otherwise rejected.
 #ifndef TRPX_TERSE_HPP
 #define TRPX_TERSE_HPP
 
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <limits>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -193,6 +195,23 @@ private:
     template <typename Iterator>
     void f_compress(Iterator data, std::size_t n_frames) {                        // Terse.hpp:500-549 -> device
         using V = typename std::iterator_traits<Iterator>::value_type;
+        if constexpr (sizeof(V) == 8) {
+            // 64-bit integers (what src/terse.cpp:120-123 makes of float / double images): the stream of values that fit
+            // 32 bits is the same whatever the container's type, so they are narrowed here; wider values are refused --
+            // the device path has no 64-bit fields.
+            static_assert(std::is_integral_v<V>, "trpx::Terse: pixel type must be integral");
+            using N = std::conditional_t<std::is_signed_v<V>, std::int32_t, std::uint32_t>;
+            std::vector<N> narrow(d_size * n_frames);
+            Iterator it = data;
+            for (N& x : narrow) {
+                const V v = *it++;
+                if (v < (V)std::numeric_limits<N>::min() || v > (V)std::numeric_limits<N>::max())
+                    throw std::invalid_argument("Terse::push_back: a 64-bit value needs more than 32 bits (not supported on the GPU path)");
+                x = (N)v;
+            }
+            f_compress(narrow.data(), n_frames);
+            return;
+        } else {
         std::vector<V> tmp;
         const V* src;
         if constexpr (std::is_pointer_v<Iterator>) src = data;
@@ -210,6 +229,7 @@ private:
         d_terse_data.resize(prev + total);
         for (std::size_t f = 0; f < n_frames; ++f) d_frame_sizes.push_back(std::size_t(offs[f + 1] - offs[f]));
         d_prolix_bits = std::max(d_prolix_bits, pb);                              // Terse.hpp:516
+        }
     }
 
     void f_read(std::ifstream& istream) {

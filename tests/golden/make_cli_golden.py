@@ -59,6 +59,10 @@ def main():
         "u16_bigendian_24x24": (bg((2, 24, 24)).astype(np.uint16), True),
         "u32_single_32x8": ((bg((1, 8, 32)).astype(np.uint32) * 70001), False),
         "i32_stack2_12x12": (((bg((2, 12, 12)) - 2) * 100003).astype(np.int32), False),
+        # float / double pixels: the reference converts them to 64-bit integers first (terse.cpp:120-123)
+        # -- as a plain vector, so the file carries no dimensions and `prolix` assumes a square image (prolix.cpp:64-65)
+        "f32_single_12x12": ((bg((1, 12, 12)) - 2).astype(np.float32) + np.float32(0.75), False),
+        "f64_stack2_8x8": ((bg((2, 8, 8)) * 3 - 4).astype(np.float64) - 0.5, False),
     }
     os.makedirs(OUT, exist_ok=True)
     index = {}
@@ -73,12 +77,16 @@ def main():
             shutil.copy(trpx, os.path.join(OUT, name + ".trpx"))
             # What `prolix` must write (prolix.cpp:69-92): 16-bit pixels when prolix_bits <= 16, else 32-bit, same
             # signedness, little endian, the reference writer's layout.
-            out_dt = np.dtype(("i" if frames.dtype.kind == "i" else "u") + ("2" if frames.dtype.itemsize <= 2 else "4"))
+            if frames.dtype.kind == "f":                     # truncation towards zero, then signed data of <= 16 bits here
+                ints, out_dt = np.trunc(frames).astype(np.int64), np.dtype("i2")
+            else:
+                ints = frames
+                out_dt = np.dtype(("i" if frames.dtype.kind == "i" else "u") + ("2" if frames.dtype.itemsize <= 2 else "4"))
             expect = os.path.join(OUT, name + ".expect.tif")
-            write_tiff(expect, frames.astype(out_dt))
+            write_tiff(expect, ints.astype(out_dt))
             entry = {"dtype": str(frames.dtype), "shape": list(frames.shape), "big_endian": be, "expect_tif": name + ".expect.tif",
                      "reference_prolix_matches": None}
-            if frames.dtype.itemsize <= 2:   # the reference prolix writes wrong pixels for 32-bit output
+            if frames.dtype.itemsize <= 2 or frames.dtype.kind == "f":   # the reference prolix writes wrong pixels for 32-bit output
                 subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "prolix_cli"), trpx], stdout=subprocess.DEVNULL)
                 same = open(os.path.join(tmp, name + ".tif"), "rb").read() == open(expect, "rb").read()
                 entry["reference_prolix_matches"] = bool(same)   # False only for >= 3 frames: reference defects D1/D2

@@ -47,6 +47,8 @@ def test_tiff_reader_writer_match_reference_layout(name, tmp_path):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "tiff_roundtrip"])
     info = INDEX[name]
+    if np.dtype(info["dtype"]).kind == "f":
+        pytest.skip("float pixels go through the tools only (converted to 64-bit integers first, terse.cpp:120-123)")
     out = tmp_path / "out.tif"
     bits = "16" if np.dtype(info["dtype"]).itemsize <= 2 else "32"
     r = subprocess.run([exe, os.path.join(CLI, name + ".tif"), str(out), bits], capture_output=True, text=True)
@@ -87,7 +89,7 @@ def test_terse_cli_writes_the_reference_trpx(name, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Terse compressed: 1 files" in r.stdout and "Compression rate:" in r.stdout
     dtn = np.dtype(INDEX[name]["dtype"])                     # ImageJ/TRPX_Reader.java:94-98: unsigned, <= 16 bits only
-    assert ("ImageJ TRPX reader only opens" in r.stdout) == (dtn.kind == "i" or dtn.itemsize == 4)
+    assert ("ImageJ TRPX reader only opens" in r.stdout) == (dtn.kind in "if" or dtn.itemsize == 4)
     assert work.exists()                                     # kept (the reference deletes it; -delete does that here)
     assert (tmp_path / (name + ".trpx")).read_bytes() == open(os.path.join(CLI, name + ".trpx"), "rb").read()
     r = subprocess.run([exe, "-delete", str(work)], capture_output=True, text=True)
@@ -110,7 +112,7 @@ def test_prolix_cli_expands_the_reference_trpx(name, tmp_path):
     got = (tmp_path / (name + ".tif")).read_bytes()
     assert got == open(os.path.join(CLI, info["expect_tif"]), "rb").read()
     want = _parse_tiff(os.path.join(CLI, name + ".tif"))
-    assert (_parse_tiff(str(tmp_path / (name + ".tif"))).astype(np.int64) == want.astype(np.int64)).all()
+    assert (_parse_tiff(str(tmp_path / (name + ".tif"))).astype(np.int64) == np.trunc(want).astype(np.int64)).all()   # (float fixtures: truncated)
 
 
 def _indexed_trpx(name):

@@ -546,3 +546,25 @@ def test_every_decode_path_every_dtype_block_to_block_width_changes(gpu, oracle,
                 torch.cuda.synchronize()
                 assert int(st[0]) == 0, (dtype, frames, kind)
                 assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, frames, kind, rep)
+
+
+def test_64bit_integer_containers_are_narrowed_when_they_fit(gpu, oracle):
+    """int64 / uint64 input (what src/terse.cpp:120-123 makes of float images): same stream as the oracle's 64-bit
+    encode when every value fits 32 bits, refused otherwise."""
+    from trpx_amd import Terse
+    rng = np.random.RandomState(3)
+    for dt in (np.int64, np.uint64):
+        px = rng.randint(0, 2000, size=(3, 5000)).astype(np.int64)
+        px[:, ::97] *= 1000
+        if dt == np.int64:
+            px -= 700
+        px = px.astype(dt)
+        want, sizes, pb = oracle.encode_stack(px)
+        t = Terse()
+        t.push_back_stack(px)
+        assert t.data() == want.tobytes() and t.frame_sizes() == [int(x) for x in sizes] and t.bits_per_val() == pb
+        assert t.is_signed() == (dt == np.int64)
+        back = t.prolix_stack(np.int32 if dt == np.int64 else np.uint32)
+        assert (back.astype(np.int64) == px.astype(np.int64)).all()
+    with pytest.raises(ValueError):
+        Terse(np.array([0, 1 << 40], np.int64))

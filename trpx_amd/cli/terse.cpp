@@ -4,8 +4,8 @@
 // every argument with a .tif / .tiff / .TIF / .TIFF extension is read, all images of its stack are pushed into ONE
 // Terse object (one device call for the whole stack) and written next to it as <name>.trpx; -verbose prints the
 // reference's report.  Differences: the input is kept unless -delete is given (the reference always deletes it,
-// terse.cpp:82); float / double TIFFs (converted to 64-bit integers by the reference, :120-123) are refused -- the
-// device path has no 64-bit pixels.
+// terse.cpp:82); float / double TIFFs are converted to 64-bit integers like the reference does (:120-123) and encoded
+// when every value fits 32 bits -- the device path has no 64-bit fields.
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -26,6 +26,23 @@ static void compress_stack(trpx::Terse& out, trpx::Grey_tif const& tif) {
     std::vector<T> stack(n * frames);                       // the images of a TIFF file are separated by their IFDs
     for (std::size_t i = 0; i < frames; ++i) std::memcpy(stack.data() + i * n, tif.pixels(i), n * sizeof(T));
     out.dim({tif.image(0).width, tif.image(0).height});     // what push_back(image) captures from image.dim() (Terse.hpp:314-317)
+    out.push_back(stack.data(), n, frames);
+}
+
+// float / double images: converted to 64-bit integers like the reference does (static_cast, i.e. truncation towards
+// zero) and pushed as a plain vector -- which is why such files carry no `dimensions` attribute (terse.cpp:120-123).
+static void compress_float_stack(trpx::Terse& out, trpx::Grey_tif const& tif) {
+    const std::size_t n = tif.image(0).pixels(), frames = tif.image_stack_size();
+    std::vector<std::int64_t> stack(n * frames);
+    for (std::size_t i = 0; i < frames; ++i) {
+        if (tif.image(i).bytes_per_pixel == 4) {
+            float const* p = reinterpret_cast<float const*>(tif.pixels(i));
+            for (std::size_t k = 0; k < n; ++k) stack[i * n + k] = static_cast<std::int64_t>(p[k]);
+        } else {
+            double const* p = reinterpret_cast<double const*>(tif.pixels(i));
+            for (std::size_t k = 0; k < n; ++k) stack[i * n + k] = static_cast<std::int64_t>(p[k]);
+        }
+    }
     out.push_back(stack.data(), n, frames);
 }
 
@@ -82,9 +99,12 @@ int main(int argc, char const* argv[]) {
                 if (im.bytes_per_pixel != first.bytes_per_pixel || im.is_signed != first.is_signed || im.is_integral != first.is_integral)
                     throw std::runtime_error("TIFF file contains a stack of images with varying pixel types.");
             }
-            if (!first.is_integral || first.bytes_per_pixel > 4)
-                throw std::runtime_error("float / double / 64-bit pixels need 64-bit Terse data, which the GPU path does not encode.");
             trpx::Terse compressed;
+            if (!first.is_integral) {                                            // terse.cpp:119-124: float / double -> int64_t
+                compress_float_stack(compressed, tif);
+            } else if (first.bytes_per_pixel > 4)
+                throw std::runtime_error("64-bit integer pixels are not supported.");
+            else
             switch (first.bytes_per_pixel * 2 + (first.is_signed ? 1 : 0)) {      // terse.cpp:113-118
             case 2: compress_stack<std::uint8_t>(compressed, tif); break;
             case 3: compress_stack<std::int8_t>(compressed, tif); break;

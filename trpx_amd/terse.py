@@ -67,6 +67,14 @@ class Terse:
         """Append a [n_frames, ...] stack in ONE GPU call (what a detector pipeline would do)."""
         a = np.ascontiguousarray(frames)
         a = a.reshape(a.shape[0], -1)
+        if a.dtype in (np.dtype(np.int64), np.dtype(np.uint64)):
+            # 64-bit integers (what src/terse.cpp:120-123 makes of float images): values that fit 32 bits give the same
+            # stream whatever the container type, so they are narrowed here; wider ones are refused (no 64-bit fields on
+            # the device path)
+            narrow = np.int32 if a.dtype.kind == "i" else np.uint32
+            if a.size and (a.min() < np.iinfo(narrow).min or a.max() > np.iinfo(narrow).max):
+                raise ValueError("a 64-bit value needs more than 32 bits (not supported on the GPU path)")
+            a = a.astype(narrow)
         code = _code(a.dtype)
         n_frames, n = a.shape
         if n_frames == 0:
