@@ -1,0 +1,19 @@
+"""Host-pointer path (trpx_encode_host / trpx_decode_host): PCIe- and malloc-inclusive time per 2000-frame stack."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trpx_amd import _lib, codec
+from trpx_amd.terse import _code
+L = _lib.lib()
+frames, n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000, 512 * 512
+px = codec.synth(np.uint16, 0, frames, n).cpu().numpy().view(np.uint16).reshape(frames, n)
+cap = frames * L.trpx_worst_case_bytes(_lib.U16, n, 12)
+out = np.empty(cap, np.uint8); offs = np.zeros(frames + 1, np.uint64); total = C.c_size_t(0); pb = C.c_uint(0)
+back = np.empty((frames, n), np.uint16)
+for rep in range(4):
+    t0 = time.perf_counter()
+    _lib.check(L.trpx_encode_host(_lib.U16, px.ctypes.data, n, frames, 12, out.ctypes.data, cap, C.byref(total), offs.ctypes.data, C.byref(pb), -1))
+    t1 = time.perf_counter()
+    _lib.check(L.trpx_decode_host(0, _lib.U16, out.ctypes.data, total.value, offs.ctypes.data, n, frames, 12, back.ctypes.data, -1))
+    t2 = time.perf_counter()
+    print(f"rep {rep}: encode_host {1e3 * (t1 - t0):7.1f} ms ({px.nbytes / (t1 - t0) / 1e9:5.1f} GB/s of pixels)  decode_host {1e3 * (t2 - t1):7.1f} ms ({px.nbytes / (t2 - t1) / 1e9:5.1f} GB/s)  exact {bool((back == px).all())}")
