@@ -90,7 +90,11 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     // scalar adds.  Every lane decodes "its" explicit header in parallel (Terse.hpp:362-370), so the
                     // block that ends the run only has to be picked, not parsed.  (Also consuming the block AFTER that one
                     // in the same step -- an isolated odd block is two explicit headers in a row -- cut the steps per
-                    // synth-v1 frame from 602 to 436 but made each step 40 % longer: no gain, not kept.)
+                    // synth-v1 frame from 602 to 436 but made each step 40 % longer: no gain, not kept.  For streams whose width
+                    // changes every block or two, a scalar block-by-block walk over 64 dwords held in VGPRs -- two v_readlane,
+                    // a 64-bit shift, the header decode, v_writelane of the width: ~25 instructions per block -- was measured
+                    // too: 3.7 ms instead of 3.2 ms per noisy 2000-frame stack; dependent scalar chains run at ~15 clocks per
+                    // instruction here.)
                     {
                         uint32_t stride = 1u + kBlock * w_prev;
                         int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
