@@ -22,6 +22,7 @@ Profiler& profiler() {
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local bool t_force_two_pass = false;   // trpx_encode_host's retry after a look-back timeout
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -186,7 +187,7 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     }
     const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0 &&
                         (uint64_t)g.n_blocks * 396 < (1ull << 40);       // frame bits fit the fused encoder's 40-bit accumulator
-    if (g_encode_path == 0 && vec_ok)
+    if (g_encode_path == 0 && !t_force_two_pass && vec_ok)
         HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
     else {
         HIP_TRY(trpx::launch_encode(dtype, a, static_cast<hipStream_t>(stream)));
@@ -397,10 +398,10 @@ int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_fr
     uint32_t st[TRPX_STATUS_WORDS];
     HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     if (st[0] == TRPX_ERR_TIMEOUT && g_encode_path == 0) {   // never seen in practice; keeps the API total
-        g_encode_path = 1;
+        t_force_two_pass = true;                             // (this thread's next call only: other threads are not affected)
         rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
                          static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
-        g_encode_path = 0;
+        t_force_two_pass = false;
         if (rc) return rc;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
