@@ -64,14 +64,15 @@ __device__ __forceinline__ void st_desc(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum of one value per lane over the wavefront (values < 2^62): three 21-bit limbs, each summed with the DPP scan
+// ladder (64 x 2^21 < 2^32) -- the look-backs sit on every tile's critical path between packing and flush, and the
+// ds_bpermute butterfly this replaces (12 LDS-crossbar round trips) cost ~0.4 us there.
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+    const uint32_t l0 = (uint32_t)v & 0x1FFFFFu, l1 = (uint32_t)(v >> 21) & 0x1FFFFFu, l2 = (uint32_t)(v >> 42);
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(l0), 63);
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(l1), 63);
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(l2), 63);
+    return (uint64_t)s0 + ((uint64_t)s1 << 21) + ((uint64_t)s2 << 42);
 }
 
 // Decoupled look-back by one full wavefront: sum of the values of desc[lo .. idx-1], using the
