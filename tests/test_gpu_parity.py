@@ -568,3 +568,16 @@ def test_64bit_integer_containers_are_narrowed_when_they_fit(gpu, oracle):
         assert (back.astype(np.int64) == px.astype(np.int64)).all()
     with pytest.raises(ValueError):
         Terse(np.array([0, 1 << 40], np.int64))
+
+
+def test_more_frames_than_one_grid_slice(gpu, oracle):
+    """The single-pass encoder's grid is (tiles per frame, frames in slices of 32768): 40 000 tiny frames cross into
+    the second slice (and give the frame chain ~600 look-back windows)."""
+    rng = np.random.RandomState(17)
+    frames, n = 40000, 48
+    px = (rng.rand(frames, n) * (2.0 ** rng.randint(0, 12, size=(frames, 1)))).astype(np.uint16)
+    want, sizes, pb = oracle.encode_stack(px)
+    got, offs, gpb = _host_encode(px)
+    assert (np.diff(offs).astype(np.uint64) == sizes).all()
+    assert got.size == want.size and (got == want).all() and gpb == pb
+    assert (_host_decode(got, offs, n, frames, np.uint16) == px).all()
