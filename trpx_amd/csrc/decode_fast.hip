@@ -71,23 +71,24 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
 #ifdef TRPX_WALK_STATS
                 ++st_steps;
 #endif
-                const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;
+                const uint32_t fbit = frame_sh + pos + __umul24(lane, stride) - 32u * (uint32_t)c_lo;
                 const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
-                const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
-                const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
-                const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;
                 const uint64_t stop = ~__ballot((bits & 1u) != 0u);
                 const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                const uint32_t pick = first & 63u;
-                const uint32_t e_wx = (uint32_t)__builtin_amdgcn_readlane((int)wk, pick);
-                const uint32_t advx = (uint32_t)__builtin_amdgcn_readlane((int)advk, pick);
                 const bool run = first >= 64u;
-                const uint32_t e_w = run ? w_prev : e_wx, adv = run ? 0u : advx;
+                uint32_t e_w = w_prev, adv = 0;
+                if (!run) {                                                     // (wave-uniform branch)
+                    const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
+                    const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
+                    const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;
+                    e_w = (uint32_t)__builtin_amdgcn_readlane((int)wk, (int)first);
+                    adv = (uint32_t)__builtin_amdgcn_readlane((int)advk, (int)first);
+                }
                 wide = e_w > wide ? e_w : wide;
                 const uint32_t n_done = run ? 64u : first + 1u;
                 if (lane < n_done) {
                     wf[b + lane] = (uint8_t)(lane < first ? w_prev : e_w);
-                    if (((b + lane) & (kTileBlocks - 1)) == 0) tf[(b + lane) / kTileBlocks] = pos + lane * stride;
+                    if (((b + lane) & (kTileBlocks - 1)) == 0) tf[(b + lane) / kTileBlocks] = pos + __umul24(lane, stride);
                 }
                 pos += first * stride + adv;
                 b += n_done;

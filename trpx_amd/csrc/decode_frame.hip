@@ -100,23 +100,24 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
                         uint32_t wide = 0;                                // widest explicit block of these steps (checked once, after them)
                         while (b + 64u <= fast_end && (int32_t)pos < pos_max) {
-                            const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;
+                            const uint32_t fbit = frame_sh + pos + __umul24(lane, stride) - 32u * (uint32_t)c_lo;
                             const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
-                            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
-                            const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
-                            const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;   // header + payload bits
                             const uint64_t stop = ~__ballot((bits & 1u) != 0u);                           // Terse.hpp:361
                             const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                            const uint32_t pick = first & 63u;
-                            const uint32_t e_wx = (uint32_t)__builtin_amdgcn_readlane((int)wk, pick);
-                            const uint32_t advx = (uint32_t)__builtin_amdgcn_readlane((int)advk, pick);
                             const bool run = first >= 64u;                                              // all 64 repeat w_prev
-                            const uint32_t e_w = run ? w_prev : e_wx, adv = run ? 0u : advx;
+                            uint32_t e_w = w_prev, adv = 0;
+                            if (!run) {                                                                 // (wave-uniform branch)
+                                const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
+                                const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
+                                const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;   // header + payload bits
+                                e_w = (uint32_t)__builtin_amdgcn_readlane((int)wk, (int)first);
+                                adv = (uint32_t)__builtin_amdgcn_readlane((int)advk, (int)first);
+                            }
                             wide = e_w > wide ? e_w : wide;
                             const uint32_t n_done = run ? 64u : first + 1u, rel = b - s * kStepBlocks;
                             if (lane < n_done) {
                                 s_w[buf][1 + rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
-                                if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + lane * stride;
+                                if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + __umul24(lane, stride);
                             }
                             pos += first * stride + adv;                                                // (bounded by pos_max: inside the window)
                             b += n_done;
