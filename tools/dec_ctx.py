@@ -17,9 +17,13 @@ def dec():
     k = L.trpx_profile_read(buf, 8); return sum(buf[i] for i in range(k))
 for name, before in (("nothing", lambda: None), ("encode", lambda: codec.encode(px, out=enc.data, workspace=ws, frame_offsets=enc.frame_offsets, status=enc.status)),
                      ("1 GB memset", lambda: junk.zero_()), ("read 1 GB (sum)", lambda: junk.view(torch.int64).sum()),
-                     ("sleep 5 ms", lambda: (torch.cuda.synchronize(), __import__("time").sleep(0.005)))):
+                     ("sleep 5 ms", lambda: (torch.cuda.synchronize(), __import__("time").sleep(0.005))),
+                     ("encode, then read the stream", lambda: (codec.encode(px, out=enc.data, workspace=ws, frame_offsets=enc.frame_offsets, status=enc.status),
+                                                               enc.data[: 203596120].view(torch.int64).sum())),
+                     ("encode, then zero the output", lambda: (codec.encode(px, out=enc.data, workspace=ws, frame_offsets=enc.frame_offsets, status=enc.status),
+                                                               back.zero_()))):
     t = []
     for _ in range(8):
         before(); torch.cuda.synchronize()
         t.append(dec())
-    print(f"before = {name:16s}: decode {np.median(t):.4f} ms (min {min(t):.4f})")
+    print(f"before = {name:30s}: decode {np.median(t):.4f} ms (min {min(t):.4f})")

@@ -35,9 +35,12 @@ constexpr int kGroupsPerWave = TRPX_FRAME_GPW;          // 64-block groups per u
 constexpr int kStepGroups = (kFrameWaves - 1) * kGroupsPerWave;   // 64-block groups per super-step
 constexpr int kStepBlocks = kStepGroups * kWave;       // 768
 #ifndef TRPX_FRAME_CHUNK_DW
-#define TRPX_FRAME_CHUNK_DW 4096
+#define TRPX_FRAME_CHUNK_DW 2048
 #endif
-constexpr int kFrameChunkDw = TRPX_FRAME_CHUNK_DW;     // walker's stream window: 16 KB (1024 / 2048 / 4096 dwords: 0.333 / 0.326 / 0.318 ms)
+constexpr int kFrameChunkDw = TRPX_FRAME_CHUNK_DW;     // walker's stream window: 8 KB.  Stream cache-resident (decode after decode): 2 / 4 / 8 /
+                                                       // 16 KB -> 0.31 / 0.32 / 0.30 / 0.30 ms; cold (decode after an encode, the bench's round
+                                                       // trip): 0.40 / 0.37 / 0.35 / 0.40 ms -- the unpack waves re-read the window's lines from
+                                                       // L2, and 250 workgroups per XCD x 16 KB is all of its 4 MB
 
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
