@@ -69,22 +69,24 @@ int g_encode_path = [] {
     const char* e = getenv("TRPX_ENCODE_PATH");
     return e && strcmp(e, "twopass") == 0 ? 1 : 0;
 }();
-struct IdxLayout { size_t group_off, widths, total; };
+struct IdxLayout { size_t group_off, widths, seg, total; };
 IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     IdxLayout l;
     l.group_off = 0;
     l.widths = trpx::align_up(8 * n_frames * (size_t)g.n_tiles, 16);
-    l.total = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);
+    l.seg = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);   // scratch of trpx_build_index's walk
+    l.total = l.seg + trpx::seg_workspace_bytes(g, n_frames);
     return l;
 }
-struct DecWs { size_t walk_offsets, tile_off, widths, total; };
+struct DecWs { size_t walk_offsets, tile_off, widths, seg, total; };
 DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     DecWs w;
     const size_t tiles = n_frames * (size_t)g.n_tiles;
     w.walk_offsets = 0;
     w.tile_off = trpx::align_up(w.walk_offsets + 8 * (n_frames + 1), 16);
     w.widths = trpx::align_up(w.tile_off + 8 * tiles, 16);
-    w.total = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
+    w.seg = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
+    w.total = w.seg + trpx::seg_workspace_bytes(g, n_frames);
     return w;
 }
 
@@ -229,10 +231,11 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
+    a.seg_ws = ws + w.seg;
     // TRPX_DECODE_PATH = basic | tiles | frames forces one of the three decode paths (A/B checks)
     static const char* dpath = getenv("TRPX_DECODE_PATH") ? getenv("TRPX_DECODE_PATH") : "";
     static const bool basic = strcmp(dpath, "basic") == 0;
-    static const bool force_tiles = strcmp(dpath, "tiles") == 0, force_frames = strcmp(dpath, "frames") == 0;
+    static const bool force_tiles = strcmp(dpath, "tiles") == 0 || strcmp(dpath, "seg") == 0, force_frames = strcmp(dpath, "frames") == 0;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
     const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0 &&
                          block == (unsigned)trpx::kBlock;
@@ -269,6 +272,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     a.status = status;
     a.tile_off = reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off);
     a.widths = reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths);
+    a.seg_ws = static_cast<char*>(index) + il.seg;
     HIP_TRY(trpx::launch_walk_only(a, (uint32_t)(8 * trpx_dtype_size(dtype)), clear_status, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }
@@ -335,6 +339,7 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
     a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
+    a.seg_ws = ws + w.seg;
     HIP_TRY(trpx::launch_decode_convert(out_dtype, a, stream_signed != 0, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }
@@ -493,6 +498,7 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     a.walk_offsets = reinterpret_cast<uint64_t*>(ws + w.walk_offsets);
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
+    a.seg_ws = ws + w.seg;
     HIP_TRY(trpx::launch_walk_serial(a, max_bits, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     uint32_t st[TRPX_STATUS_WORDS];

@@ -18,6 +18,8 @@
 #include "encode_kernels.hpp"
 #include "profile.hpp"
 #include "unpack_common.hpp"
+#include <stdlib.h>
+#include <string.h>
 
 namespace trpx {
 
@@ -320,9 +322,10 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hip
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    if (!have_index)
-        hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                           a.frame_offsets, g, max_w, a.widths, a.tile_off, a.status);
+    if (!have_index) {
+        const hipError_t e = launch_walk_only(a, max_w, false, st);
+        if (e != hipSuccess) return e;
+    }
     prof.mark(st);
     hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
                        (uint64_t)a.terse_bytes, a.frame_offsets, g, tpf, a.widths, a.tile_off,
@@ -336,6 +339,9 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
     if (clear_status) {
         zero_status(a.status, st);
     }
+    // TRPX_WALK = lds keeps the one-wavefront-per-frame walk (A/B checks); default: the position-parallel walk
+    static const bool lds_walk = getenv("TRPX_WALK") && strcmp(getenv("TRPX_WALK"), "lds") == 0;
+    if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, nullptr, st);
     hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, a.status);
     return hipGetLastError();
