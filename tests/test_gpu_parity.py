@@ -581,3 +581,49 @@ def test_more_frames_than_one_grid_slice(gpu, oracle):
     assert (np.diff(offs).astype(np.uint64) == sizes).all()
     assert got.size == want.size and (got == want).all() and gpb == pb
     assert (_host_decode(got, offs, n, frames, np.uint16) == px).all()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_width_changes_every_block_position_parallel_walk(gpu, oracle, dtype):
+    """Streams with an explicit header on EVERY block (no two neighbouring blocks share a width; Terse.hpp:360-372 makes
+    the header chain one dependent step per block) for all six pixel types, against the oracle:
+    a 130-frame stack (per-frame decoder -> its walker defers such frames to the position-parallel walk, decode_seg.hip:
+    one wavefront per frame, several LDS windows per segment) and three large frames (tiled decoder: several wavefronts
+    per frame, links between them closed by k_seg_resolve).  Also the walk's product itself -- width[b] of every block --
+    against oracle.widths(), for the encoder's index and for the index rebuilt from the stream."""
+    import torch
+    from trpx_amd import codec
+    rng = np.random.RandomState(7)
+    dt = np.dtype(dtype)
+    top = 8 * dt.itemsize - (1 if dt.kind == "i" else 0)
+    tdt = {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
+           4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
+    choices = np.array([1, 2, 3, 4, 6, min(8, top), top])
+    for frames, n in ((130, 256 * 512), (3, 1024 * 1024 + 4)):
+        nblk = (n + 11) // 12
+        step = rng.randint(1, len(choices), size=(frames, nblk))             # never 0: the next block's width differs
+        hi = choices[np.cumsum(step, axis=1) % len(choices)]
+        mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)
+        mag[:, ::12] = (2 ** np.minimum(hi, 62) - 1)                          # the block's width is exactly hi (signed: + 1)
+        mag = mag[:, :n]
+        if dt.kind == "i":
+            mag = np.minimum(mag, 2 ** (top - 1) - 1) * rng.choice([-1, 1], size=mag.shape)
+        px = mag.astype(dt)
+        want, sizes, pb = oracle.encode_stack(px)
+        dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
+        enc = codec.encode(dpx, index=True)
+        torch.cuda.synchronize()
+        enc.check()
+        assert enc.stack().cpu().numpy().tobytes() == want.tobytes(), (dtype, frames)
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt)
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0, (dtype, frames)
+        assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, frames)
+        walked = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, dt)
+        torch.cuda.synchronize()
+        ng = (nblk + 255) // 256
+        w_off = (8 * frames * ng + 15) // 16 * 16
+        want_w = np.stack([oracle.widths(px[f]) for f in range(frames)]).astype(np.uint8)
+        for name, idx in (("encoder", enc.index), ("walk", walked)):
+            got_w = idx[w_off: w_off + frames * nblk].cpu().numpy().reshape(frames, nblk)
+            assert (got_w == want_w).all(), (dtype, frames, name)

@@ -78,7 +78,7 @@ IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     l.total = l.seg + trpx::seg_workspace_bytes(g, n_frames);
     return l;
 }
-struct DecWs { size_t walk_offsets, tile_off, widths, seg, total; };
+struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, total; };
 DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     DecWs w;
     const size_t tiles = n_frames * (size_t)g.n_tiles;
@@ -86,7 +86,8 @@ DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     w.tile_off = trpx::align_up(w.walk_offsets + 8 * (n_frames + 1), 16);
     w.widths = trpx::align_up(w.tile_off + 8 * tiles, 16);
     w.seg = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
-    w.total = w.seg + trpx::seg_workspace_bytes(g, n_frames);
+    w.defer = w.seg + trpx::seg_workspace_bytes(g, n_frames);
+    w.total = w.defer + trpx::align_up(4 * (n_frames + 2), 256);
     return w;
 }
 
@@ -219,7 +220,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     if (workspace_bytes < w.total)
         return fail(TRPX_ERR_CAPACITY, "trpx_decode: workspace %zu < %zu", workspace_bytes, w.total);
 
-    trpx::DecodeArgs a;
+    trpx::DecodeArgs a{};
     a.terse = terse;
     a.terse_bytes = terse_bytes;
     a.frame_offsets = frame_offsets;
@@ -232,6 +233,8 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
     a.seg_ws = ws + w.seg;
+    static const bool no_defer = getenv("TRPX_NO_DEFER") != nullptr;          // (A/B checks: the per-frame decoder keeps every frame)
+    a.defer = no_defer ? nullptr : reinterpret_cast<uint32_t*>(ws + w.defer);
     // TRPX_DECODE_PATH = basic | tiles | frames forces one of the three decode paths (A/B checks)
     static const char* dpath = getenv("TRPX_DECODE_PATH") ? getenv("TRPX_DECODE_PATH") : "";
     static const bool basic = strcmp(dpath, "basic") == 0;
@@ -486,7 +489,7 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     HIP_TRY(d_ws.alloc(w.total));
     HIP_TRY(hipMemset(d_in.p, 0, trpx::align_up(terse_bytes, 4) + 8));
     HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
-    trpx::DecodeArgs a;
+    trpx::DecodeArgs a{};
     a.terse = static_cast<const uint8_t*>(d_in.p);
     a.terse_bytes = terse_bytes;
     a.frame_offsets = nullptr;

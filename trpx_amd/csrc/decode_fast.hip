@@ -18,6 +18,7 @@
 #include "encode_kernels.hpp"
 #include "profile.hpp"
 #include "unpack_common.hpp"
+#include "unpack_tile.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -31,10 +32,12 @@ constexpr int kWalkChunkDw = 4096;                    // 16 KB of stream per LDS
 __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                     uint32_t max_w, uint8_t* __restrict__ widths,
-                                                    uint64_t* __restrict__ tile_off, uint32_t* __restrict__ status) {
+                                                    uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ only,
+                                                    uint32_t* __restrict__ status) {
     __shared__ uint32_t s_chunk[kWalkChunkDw + 4];
     const uint32_t lane = (uint32_t)lane_id();
     const uint64_t frame = blockIdx.x;
+    if (only && !only[frame]) return;                 // (frames the position-parallel walk has done)
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     if (!(fe > fo && fe <= terse_bytes)) {
         if (lane == 0) atomicMax(&status[0], 5u);
@@ -192,10 +195,6 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // k_unpack_tiles
 // ---------------------------------------------------------------------------------------------
-template <typename T> constexpr int unpack_sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
-template <typename T>
-constexpr int unpack_image_dwords() { return unpack_sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 12; }
-
 template <typename T>
 __global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
@@ -203,113 +202,12 @@ __global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __r
                                                               const uint8_t* __restrict__ widths,
                                                               const uint64_t* __restrict__ tile_off,
                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
-    constexpr int kSub = unpack_sub_tiles<T>();
-    constexpr int kImage = unpack_image_dwords<T>();
-    __shared__ uint32_t s_image[kImage];
-    __shared__ uint32_t s_wtot[kSub * 4];
+    __shared__ uint32_t s_image[unpack_image_dwords<T>()];
+    __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
     if (status[0] != 0) return;                             // corrupt chain: produce nothing
-    const uint32_t tid = threadIdx.x;
-    const int lane = lane_id(), wave = wave_id();
     const uint64_t tile = blockIdx.x;
-    const uint32_t frame = (uint32_t)(tile / tiles_per_frame);
-    const uint32_t t = (uint32_t)(tile % tiles_per_frame);
-    const uint32_t b0 = t * kSub * kThreads;
-    const uint8_t* __restrict__ wf = widths + (uint64_t)frame * g.n_blocks;
-
-    uint32_t w[kSub], hl[kSub], len[kSub], inc[kSub];
-    int nb[kSub];
-#pragma unroll
-    for (int r = 0; r < kSub; ++r) {
-        const uint32_t b = b0 + r * kThreads + tid;
-        nb[r] = 0; w[r] = 0; hl[r] = 0;
-        if (b < g.n_blocks) {
-            w[r] = wf[b];
-            const uint32_t w_prev = b ? wf[b - 1] : 0u;     // significant_bits = 0 at frame start (Terse.hpp:359)
-            const uint64_t first = (uint64_t)b * kBlock;
-            nb[r] = first + kBlock <= g.n_values ? kBlock : (int)(g.n_values - first);
-            hl[r] = header_len(w[r], w_prev);
-        }
-        len[r] = nb[r] ? hl[r] + (uint32_t)nb[r] * w[r] : 0u;
-        inc[r] = wave_inclusive_scan(len[r]);
-        if (lane == 63) s_wtot[r * 4 + wave] = inc[r];
-    }
-    __syncthreads();
-    // every wave: exclusive scan of the 16 (round, wave) piece sizes
-    uint32_t off[kSub];
-    uint32_t tile_bits;
-    {
-        const uint32_t tot = lane < kSub * 4 ? s_wtot[lane] : 0u;
-        const uint32_t incl = wave_inclusive_scan(tot);
-        const uint32_t excl = incl - tot;
-#pragma unroll
-        for (int r = 0; r < kSub; ++r)
-            off[r] = (uint32_t)__shfl((int)excl, r * 4 + wave, 64) + inc[r] - len[r];   // tile-relative bit of my block
-        tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, kSub * 4 - 1);
-    }
-    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
-    const uint64_t t_off = tile_off[(uint64_t)frame * g.n_tiles + (uint64_t)t * kSub];   // walk records every 256 blocks
-    if (fe > terse_bytes || fe <= fo || t_off > 8 * (fe - fo) || tile_bits > 8 * (fe - fo) - t_off) {   // chain / index inconsistent with the frame
-        if (tid == 0) atomicMax(&status[0], 5u);
-        return;
-    }
-    // ---- stage the tile's stream bits [a0, a0 + tile_bits) in LDS, 16 bytes per lane, coalesced ----------
-    const uint64_t a0 = 8 * fo + t_off;
-    const uint64_t d_lo = (a0 >> 5) & ~3ull;                 // 16-byte aligned start (terse is 4-byte aligned: use dwords)
-    const uint32_t n_dw = (uint32_t)(((a0 + tile_bits + 31) >> 5) - d_lo) + 1;   // + 1: alignbit peeks one dword further
-    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(terse);
-    const uint64_t total_dw = (terse_bytes + 3) / 4;
-    const bool base16 = ((uintptr_t)terse & 15) == 0;
-    for (uint32_t i = tid * 4; i < n_dw; i += kThreads * 4) {
-        const uint64_t d = d_lo + i;
-        uint4 x;
-        if (base16 && d + 4 <= total_dw) x = *reinterpret_cast<const uint4*>(s32 + d);
-        else {
-            x.x = d < total_dw ? s32[d] : 0u; x.y = d + 1 < total_dw ? s32[d + 1] : 0u;
-            x.z = d + 2 < total_dw ? s32[d + 2] : 0u; x.w = d + 3 < total_dw ? s32[d + 3] : 0u;
-        }
-        *reinterpret_cast<uint4*>(&s_image[i]) = x;
-    }
-    __syncthreads();
-    const uint32_t img_bit0 = (uint32_t)(a0 - 32 * d_lo);   // image bit of the tile's first bit (< 128)
-
-    // ---- extract + store ----------------------------------------------------------------------------------
-    T* __restrict__ fout = pixels_out + (uint64_t)frame * g.n_values;
-#pragma unroll
-    for (int r = 0; r < kSub; ++r) {
-        const uint32_t b = b0 + r * kThreads + tid;
-        const uint32_t q = img_bit0 + off[r] + hl[r];       // first payload bit in the image
-        uint32_t u[kBlock];
-#pragma unroll
-        for (int k = 0; k < kBlock; ++k) u[k] = 0u;         // w == 0 -> zeros (Terse.hpp:373-374)
-        uint64_t todo = __ballot(nb[r] == kBlock && w[r] != 0u);
-        while (todo) {
-            const int l0 = __builtin_ctzll(todo);
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w[r], l0);
-            const bool mine = nb[r] == kBlock && w[r] == w0;
-            uint32_t qq = q;
-            asm volatile("" : "+v"(qq));                    // keep the specialised bodies out of LICM's reach
-            if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(s_image, qq, w0 > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w0, u);
-            todo &= ~__ballot(mine);
-        }
-        if (nb[r] == kBlock) {
-            if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
-            store_block<T>(fout + (uint64_t)b * kBlock, u);
-        } else if (nb[r]) {                                 // the frame's last, partial block: generic
-            const uint32_t ww = w[r] > (uint32_t)PixelTraits<T>::bits ? 0u : w[r];
-            const uint32_t mask = ww >= 32u ? 0xFFFFFFFFu : ((1u << ww) - 1u);
-            uint32_t p = q;
-            for (int k = 0; k < nb[r]; ++k) {
-                uint32_t f = 0;
-                if (ww) {
-                    const uint64_t two = (uint64_t)s_image[p >> 5] | ((uint64_t)s_image[(p >> 5) + 1] << 32);
-                    f = (uint32_t)(two >> (p & 31u)) & mask;
-                    if (PixelTraits<T>::is_signed) f = (uint32_t)((int32_t)(f << (32u - ww)) >> (32u - ww));
-                }
-                fout[(uint64_t)b * kBlock + k] = (T)f;
-                p += ww;
-            }
-        }
-    }
+    unpack_tile<T>(terse, terse_bytes, frame_offsets, g, (uint32_t)(tile / tiles_per_frame), (uint32_t)(tile % tiles_per_frame),
+                   widths, tile_off, pixels_out, status, s_image, s_wtot);
 }
 
 template <typename T>
@@ -334,6 +232,8 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hip
     return hipGetLastError();
 }
 
+hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st);
+
 // Fast path preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned.
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
     if (clear_status) {
@@ -341,9 +241,13 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
     }
     // TRPX_WALK = lds keeps the one-wavefront-per-frame walk (A/B checks); default: the position-parallel walk
     static const bool lds_walk = getenv("TRPX_WALK") && strcmp(getenv("TRPX_WALK"), "lds") == 0;
-    if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, nullptr, st);
+    if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, st);
+    return launch_walk_lds_only(a, max_w, nullptr, st);
+}
+
+hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st) {
     hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                       a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, a.status);
+                       a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, only, a.status);
     return hipGetLastError();
 }
 

@@ -45,7 +45,8 @@ constexpr int kFrameChunkDw = TRPX_FRAME_CHUNK_DW;     // walker's stream window
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
-                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
+                                                               uint32_t* __restrict__ status) {
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
     __shared__ uint32_t s_chunk[kFrameChunkDw + 4];    // walker's window of the stream
     __shared__ uint8_t s_w[2][kStepBlocks + 4];        // [0] = width of the block before the super-step, [1 + i] = widths of its blocks (double buffered)
@@ -195,6 +196,20 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 if (!bad && b == n_blocks)                                            // S_f = 1 + bits/8 (Terse.hpp:547)
                     bad = !(final_pos <= limit && 1 + (uint64_t)final_pos / 8 == fe - fo);
                 if (bad && lane == 0) s_err = 1u;
+                // A stream with an explicit header every few blocks costs this walker a step per header (10 x the time of a
+                // run-dominated frame); false chains merge quickly in such streams, so the frame goes to the
+                // position-parallel walk instead (decode_seg.hip).  Decided after super-steps 0, 3 and 11 on the width
+                // changes inside the super-step just walked (12 widths per lane, outside the step loop).
+                if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_b == (s + 1) * kStepBlocks && end_b < n_blocks) {
+                    uint32_t changes = 0;
+#pragma unroll
+                    for (int i = 0; i < kStepBlocks / kWave; ++i) {
+                        const uint32_t at = lane * (kStepBlocks / kWave) + i;
+                        changes += s_w[buf][at] != s_w[buf][at + 1] ? 1u : 0u;
+                    }
+                    const uint32_t inc = wave_inclusive_scan(changes);
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > (uint32_t)kStepBlocks && lane == 0) s_err = 2u;
+                }
             }
 #ifdef TRPX_DEC_WALK_ONLY
         } else if (false) {                            // diagnostic build (tools): time the walker alone
@@ -222,6 +237,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     hl = header_len(w, wp);
                     nb = blk + 1 == n_blocks ? (int)nb_last : kBlock;
                 }
+
                 const uint32_t len = nb ? hl + __umul24((uint32_t)nb, w) : 0u;
                 const uint32_t inc = wave_inclusive_scan(len);
                 const uint32_t q = frame_sh + s_goff[pbuf][gi] + (inc - len) + hl;    // first payload bit, relative to dword frame_dw
@@ -278,18 +294,29 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
         __syncthreads();                               // super-step boundary: widths of step s published, step s-1 consumed
         if (s_err) break;
     }
-    if (s_err && threadIdx.x == 0) atomicMax(&status[0], 5u);              // TRPX_ERR_CORRUPT
+    const bool deferred = s_err == 2u;
+    if (s_err == 1u && threadIdx.x == 0) atomicMax(&status[0], 5u);        // TRPX_ERR_CORRUPT
+    if (deferred && threadIdx.x == 0) defer[1u + atomicAdd(&defer[0], 1u)] = (uint32_t)frame;   // listed: k_seg_frames + k_unpack_listed do it
 }
 
 template <typename T>
 static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
-    zero_status(a.status, st);
+    uint32_t* defer = a.defer && a.seg_ws && seg_single_wave(a.geom) ? a.defer : nullptr;
+    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(defer), (uint64_t)(defer ? 1 : 0),
+                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)4);   // status block + the deferred-frame count
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
     hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                       a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status);
+                       a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), defer, a.status);
     prof.mark(st);
+    if (defer) {
+        const hipError_t e = launch_decode_deferred(PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
+                                                    : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2)
+                                                                                 : (PixelTraits<T>::is_signed ? 5 : 4), a, st);
+        prof.mark(st);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 

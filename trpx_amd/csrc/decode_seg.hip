@@ -11,16 +11,21 @@
 //   segments      the frame's bit range is cut at X_j = j * L (G segments, L a multiple of 128 bits).  Lane j
 //                 owns the blocks whose header starts in [X_j, X_j+1).  Its IN state is the first block start
 //                 at or after X_j and the width before it; its OUT state is the same thing at X_j+1.
-//   speculation   lane 0 starts from the true state (0, 0) (Terse.hpp:359).  Every other lane first starts from
-//                 the guess (X_j, 0).  A wrong chain and the true chain merge as soon as they meet at an explicit
-//                 header, or at any block start with equal widths -- which they do within a few hundred blocks on
-//                 real data -- so most guessed lanes still END in the true state.
+//   speculation   lane 0 starts from the true state (0, 0) (Terse.hpp:359).  Every other lane starts from a guess:
+//                 (X_j, 0) -- a wrong chain and the true chain merge as soon as they meet at an explicit header, or
+//                 at any block start with equal widths, which on streams with frequent explicit headers happens
+//                 within a few dozen blocks, so a guessed lane still ENDS in the true state -- or, where the stream
+//                 is a run of equal-width blocks (nothing to merge at), a position inside the run found by its
+//                 periodic header bits (seg_comb_guess; the lane's boundary B_j moves there).
 //   fix point     in_j <- out_(j-1), re-walk the lanes whose IN state changed, repeat until nothing changes.
 //                 in_0 is true and in_(j+1) = F_j(in_j) for every j, hence by induction every state is the true
-//                 one; at most G rounds, typically 2-4.  Inside a wavefront the rounds are a loop (states move one
-//                 lane up with a DPP/LDS shuffle); across wavefronts of one frame the last OUT state of wave k-1
+//                 one; at most G rounds, typically 2-4.  Which of two conflicting states a lane believes (its own
+//                 run guess or its predecessor's OUT state) only steers the speed, see seg_fixpoint.  Inside a
+//                 wavefront the rounds are a loop; across wavefronts of one frame the last OUT state of wave k-1
 //                 is read from memory by wave k on the next launch, and k_seg_resolve re-checks every such link
-//                 (and re-runs a wave serially if one is still open) before anything is written.
+//                 (and re-runs a wave serially if one is still open) before anything is written.  A frame that
+//                 does not converge (long runs of wide blocks: nothing to merge at, no guess) is handed to the
+//                 serial walk (k_walk_lds), so the worst case is the old one.
 //   write pass    block counts -> prefix sum -> every lane walks its segment once more from its verified IN
 //                 state and stores width[b] (u8, array pre-zeroed: zero widths are not stored) and the bit
 //                 offset of every 256-block group: the same decode index k_walk_lds emits, consumed by
@@ -35,13 +40,16 @@
 #include "codec_common.hpp"
 #include "encode_kernels.hpp"
 #include "profile.hpp"
+#include "unpack_tile.hpp"
+#include <stdlib.h>
 
 namespace trpx {
 
 constexpr uint32_t kSegAdv = 768;                 // bits a window advances
-constexpr uint32_t kSegWinDw = 32;                // dwords loaded per window: 127 (alignment) + 768 + 44 (peek) bits <= 1024
+//                                                   (32 dwords are loaded per window: 127 (alignment) + 768 + 44 (peek) bits <= 1024)
 constexpr uint32_t kSegRow = 36;                  // LDS dwords per lane window (16-byte aligned rows)
-constexpr uint32_t kSegLiveMargin = 400;          // > longest block (12 + 12 * 32 bits): see seg_last_live()
+constexpr uint32_t kSegSpan = 864;                // window bits a first-round guess may use (boundaries move by < kSegSpan)
+constexpr uint32_t kSegLiveMargin = 400 + kSegSpan;   // > longest block (12 + 12 * 32 bits) + boundary shift: see seg_last_live()
 
 typedef uint32_t seg_u4 __attribute__((ext_vector_type(4)));
 
@@ -53,6 +61,7 @@ struct SegCtx {
     uint32_t L;              // segment length in bits (multiple of 128)
     uint32_t wsh;            // fa & 127: bit offset of a window's first wanted bit inside its 16-byte aligned load
     uint32_t n_blocks, nb_last, max_w;
+    uint32_t* stat;          // status block (diagnostic build: [2] rounds, [3] wave steps, [4] lane walks)
 };
 
 __device__ __forceinline__ uint64_t seg_pack(uint32_t pos, uint32_t w) { return (uint64_t)pos | ((uint64_t)w << 32); }
@@ -122,28 +131,33 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         fetch(t + 1, live);                                   // prefetch: consumed at the top of the next iteration
         const uint32_t w0 = X + t * kSegAdv, wend = w0 + kSegAdv;
         bool act = !done && pos < wend;
+        // Every lane executes every step (no exec-mask juggling, one branch per step); a lane that is not active
+        // computes on a stale position and keeps its state.
         while (__ballot(act)) {
-            if (act) {
-                const uint32_t li = pos - w0 + c.wsh;                                     // bit index inside the lane's window
-                const uint32_t* row = win + lane * kSegRow + (li >> 5);
-                const uint32_t bits = __builtin_amdgcn_alignbit(row[1], row[0], li);      // 32 stream bits from pos
-                const bool same = (bits & 1u) != 0u;                                      // Terse.hpp:361
-                const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
-                const uint32_t wx = w3 != 7u ? w3 : (wa != 10u ? wa : wb);                // Terse.hpp:362-370
-                const uint32_t hx = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
-                uint32_t wn = same ? w : wx;
-                if (wn > c.max_w) { wn = 0u; if (WRITE) bad = true; }
-                uint32_t rep = 1u, len;
-                if (same && wn == 0u) {                                                   // run of empty blocks: 1 bit each
-                    rep = (uint32_t)__builtin_ctz(~bits | 0x80000000u) + ((bits == 0xFFFFFFFFu) ? 1u : 0u);
-                    const uint32_t room = WRITE && by_count ? c.n_blocks - n : end - pos;
-                    rep = rep < room ? rep : room;
-                    len = rep;
-                } else {
-                    const uint32_t nv = WRITE && n + 1u == c.n_blocks ? c.nb_last : (uint32_t)kBlock;
-                    len = (same ? 1u : hx) + nv * wn;
-                }
-                if (WRITE) {
+#ifdef TRPX_SEG_STATS
+            if (lane == 0u) atomicAdd(c.stat + 3, 1u);
+#endif
+            const uint32_t li = pos - w0 + c.wsh;                                         // bit index inside the lane's window
+            const uint32_t dw = min(li >> 5, kSegRow - 2u);                               // (an inactive lane may be past its row)
+            const uint32_t* row = win + lane * kSegRow + dw;
+            const uint32_t bits = __builtin_amdgcn_alignbit(row[1], row[0], li);          // 32 stream bits from pos
+            const bool same = (bits & 1u) != 0u;                                          // Terse.hpp:361
+            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
+            const uint32_t wx = w3 != 7u ? w3 : (wa != 10u ? wa : wb);                    // Terse.hpp:362-370
+            const uint32_t hx = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
+            uint32_t wn = same ? w : wx;
+            const bool wide = wn > c.max_w;
+            wn = wide ? 0u : wn;
+            // a run of empty blocks (header bits 1, no payload: 1 bit each) is taken up to 32 blocks at a time
+            const bool zrun = same && wn == 0u;
+            const uint32_t ones = min((uint32_t)(__ffs((int)~bits) - 1), 32u);
+            const uint32_t room = WRITE && by_count ? c.n_blocks - n : end - pos;
+            const uint32_t rep = zrun ? min(ones, room) : 1u;
+            const uint32_t nv = WRITE && n + 1u == c.n_blocks ? c.nb_last : (uint32_t)kBlock;
+            const uint32_t len = zrun ? rep : (same ? 1u : hx) + nv * wn;
+            if (WRITE) {
+                if (act) {
+                    bad = bad || wide;
                     if (n + rep > c.n_blocks) { bad = true; done = true; }
                     else {
                         if (wn) wf[n] = (uint8_t)wn;
@@ -151,12 +165,14 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                         if (m < n + rep) tf[m / kTileBlocks] = pos + (m - n);               // rep > 1 only for 1-bit blocks
                     }
                 }
-                pos += len; n += rep; w = wn;
-                if (WRITE && by_count) done = done || n >= c.n_blocks;
-                else done = done || pos >= end;
-                if (pos > c.limit) { done = true; if (WRITE) bad = bad || n < c.n_blocks || !by_count; }
-                act = !done && pos < wend;
             }
+            pos = act ? pos + len : pos;
+            n = act ? n + rep : n;
+            w = act ? wn : w;
+            done = done || (act && (WRITE && by_count ? n >= c.n_blocks : pos >= end));
+            if (WRITE) { if (act && pos > c.limit) bad = bad || n < c.n_blocks || !by_count; }
+            done = done || pos > c.limit;
+            act = !done && pos < wend;
         }
         __builtin_amdgcn_wave_barrier();                      // every lane is through with this window before it is overwritten
         live = __ballot(!done);
@@ -164,9 +180,50 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
     }
 }
 
+// First-round guess for run-dominated streams.  Inside a run of equal-width blocks the headers are single 1 bits
+// at stride s = 1 + 12 w, and a false chain almost never merges into such a run (it would have to hit a block start
+// with the right width by chance).  So every lane looks in the first window of its segment for the smallest
+// w in 1..4 and then the first position q whose R header bits q, q + s, ..., q + (R-1) s are all 1 (bit-parallel: 32
+// positions per AND chain; R = 12..32 so that the evidence spans ~560 bits), and, if it finds one, moves its
+// boundary there and starts from (X + q, w).  Payload bits can pass the test too (a sign bit that is mostly 1):
+// the guess is only a guess -- it is verified like any other state, see seg_fixpoint.  Inside a run of empty
+// blocks (all bits 1) the plain start (X, 0) is itself a true state and is kept; runs wider than 4 bits do not fit
+// the window often enough.
+// Returns ~0 when there is no candidate.
+__device__ __forceinline__ uint64_t seg_comb_guess(const SegCtx& c, const uint32_t* __restrict__ win, uint32_t X) {
+    const uint32_t* row = win + (uint32_t)lane_id() * kSegRow;
+    uint64_t best = ~0ull;
+    {   // a run of empty blocks (every bit a header bit 1): (X, 0) is a true state, keep it
+        uint32_t a = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < 3u; ++k) {
+            const uint32_t q = c.wsh + 32u * k;
+            a &= __builtin_amdgcn_alignbit(row[(q >> 5) + 1u], row[q >> 5], q);
+        }
+        if (a == 0xFFFFFFFFu) best = seg_pack(X, 0u);
+    }
+    const uint32_t w_hi = c.max_w < 4u ? c.max_w : 4u;
+    for (uint32_t w = 1; w <= w_hi; ++w) {
+        const uint32_t s = 1u + (uint32_t)kBlock * w;
+        const uint32_t r0 = 560u / s, R = r0 < 12u ? 12u : (r0 > 32u ? 32u : r0);
+        const uint32_t fit = kSegSpan - (R - 1u) * s - 12u, range = w < 3u ? (4u * s < fit ? 4u * s : fit) : fit;
+        const uint32_t words = (range + 31u) / 32u;
+        for (uint32_t i = 0; i < words; ++i) {
+            uint32_t a = i + 1u == words && (range & 31u) ? (1u << (range & 31u)) - 1u : 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < R; ++k) {
+                const uint32_t q = c.wsh + 32u * i + k * s;                                   // (wave-uniform)
+                a &= __builtin_amdgcn_alignbit(row[(q >> 5) + 1u], row[q >> 5], q);
+            }
+            if (a && best == ~0ull) best = seg_pack(X + 32u * i + (uint32_t)__builtin_ctz(a), w);
+        }
+        if (!__ballot(best == ~0ull)) break;
+    }
+    return best;
+}
+
 // Frame-constant part of the context.
 __device__ __forceinline__ bool seg_ctx(SegCtx& c, const uint8_t* terse, uint64_t terse_bytes, const uint64_t* frame_offsets,
-                                        uint64_t frame, const FrameGeom& g, uint32_t max_w, uint32_t G) {
+                                        uint64_t frame, const FrameGeom& g, uint32_t max_w, uint32_t G, uint32_t* status) {
+    c.stat = status;
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     if (!(fe > fo && fe <= terse_bytes) || 8 * (fe - fo) >= 0xF0000000ull) return false;
     c.s32 = reinterpret_cast<const uint32_t*>(terse);
@@ -186,50 +243,109 @@ __device__ __forceinline__ uint64_t seg_shfl_up1(uint64_t v) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// Fix-point rounds of wave k of a frame (segments 64 k .. 64 k + 63).  `first`: no earlier launch has left
-// states behind (start from the guesses).  Lane 0 of a wave k > 0 takes wave k-1's last OUT state as its IN state
-// when `link` is set.  Leaves in / out / cnt of its 64 segments in memory.
+// Segment states of one frame (device memory, seg_workspace_bytes()).
+struct SegState {
+    uint64_t* in;        // IN state of every segment
+    uint64_t* out;       // OUT state
+    uint32_t* cnt;       // blocks counted; bit 31: the IN state is still the lane's own run guess ("strong")
+    uint32_t* bnd;       // boundary B_j (X_j unless a run guess moved it)
+    uint32_t* base;      // blocks in front of the segment (k_seg_resolve)
+    uint32_t* open;      // per wave: a link inside the wave is still open
+};
+
+// Fix-point rounds of wave k of a frame (segments 64 k .. 64 k + 63).  `first`: no earlier launch has left states
+// behind (start from the guesses).  `lane0_true`: the wave's first IN state is the true one (wave 0, or a re-run by
+// k_seg_resolve) or at least the best there is (second launch: wave k-1's last OUT state).
+//
+// A lane whose IN state differs from its predecessor's OUT state (an open link) has to decide whom to believe.
+// A lane without a run guess always takes the predecessor's state.  A lane WITH one ("strong") takes it when the
+// predecessor can be trusted -- every link up to it is closed and lane 0 is true, or at least the predecessor's own
+// IN state was hit by the chain before it -- and otherwise only tries it: it walks from it and keeps it if that chain
+// ends where its own did (merged: nothing downstream changes), else it returns to its guess and waits.
+// The first open link of a wave with a true lane 0 is always taken, so the loop ends with all links closed there.
 __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restrict__ win, uint32_t k, uint32_t jl, bool first,
-                                             bool link, uint64_t* __restrict__ s_in, uint64_t* __restrict__ s_out,
-                                             uint32_t* __restrict__ s_cnt) {
+                                             bool lane0_true, int max_rounds, const SegState& st) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t j = 64u * k + lane;
     const bool walks = j < jl;                                 // lane jl and the lanes behind it own no counted blocks
-    uint64_t in = first ? seg_pack(j * c.L, 0u) : s_in[j];
-    uint64_t out = first ? 0ull : s_out[j];
-    uint32_t cnt = first ? 0u : s_cnt[j];
-    bool dirty = first && walks;
-    if (j == 0u) in = 0ull;                                    // the frame starts with width 0 at bit 0 (Terse.hpp:359, :505)
-    if (lane == 0u && k > 0u && link) {
-        const uint64_t ni = __hip_atomic_load(&s_out[j - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t in = seg_pack(j * c.L, 0u), out = 0ull;
+    uint32_t cnt = 0u, B = j * c.L;
+    bool strong = false, dirty = walks;
+    if (!first) {
+        in = st.in[j]; out = st.out[j]; B = st.bnd[j];
+        const uint32_t cs = st.cnt[j];
+        cnt = cs & 0x7FFFFFFFu; strong = (cs >> 31) != 0u; dirty = false;
+    } else if (__ballot(walks)) {                              // run-dominated streams: start inside a run
+        const uint32_t oct = lane & ~7u, piece = lane & 7u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint64_t d0 = ((c.fa + (uint64_t)(64u * k + oct + q) * c.L) >> 5) & ~3ull;
+            *reinterpret_cast<seg_u4*>(&win[(oct + q) * kSegRow + 4u * piece]) = seg_load16(c, d0 + 4u * piece);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint64_t gs = seg_comb_guess(c, win, j * c.L);
+        if (gs != ~0ull && lane > 0u && walks) { in = gs; B = (uint32_t)gs; strong = true; }   // (lane 0: the next wave's lane 63 ends at X)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j == 0u) { in = 0ull; B = 0u; strong = false; }       // the frame starts with width 0 at bit 0 (Terse.hpp:359, :505)
+    if (lane == 0u && k > 0u && !first) {
+        const uint64_t ni = __hip_atomic_load(&st.out[j - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ni != in) { in = ni; dirty = walks; }
     }
-    for (int iter = 0; iter < 66; ++iter) {
+    uint32_t endB = (uint32_t)__shfl_down((int)B, 1, 64);
+    if (lane == 63u) endB = (j + 1u) * c.L;
+    bool tent = false, conflict = false;
+    uint64_t sav_in = 0ull, sav_out = 0ull, rej = ~0ull;
+    uint32_t sav_cnt = 0u;
+    for (int iter = 0; iter < max_rounds; ++iter) {
         if (!__ballot(dirty)) break;
+#ifdef TRPX_SEG_STATS
+        if (lane == 0u) { atomicAdd(c.stat + 2, 1u); atomicAdd(c.stat + 4, (uint32_t)__builtin_popcountll(__ballot(dirty))); }
+#endif
         uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
         bool bad = false;
-        seg_walk<false>(c, win, 64u * k, dirty, (j + 1u) * c.L, false, pos, w, n, nullptr, nullptr, bad);
-        if (dirty) { out = seg_pack(pos, w); cnt = n; }
+        seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
+        if (dirty) {
+            const uint64_t o = seg_pack(pos, w);
+            if (tent) {
+                if (o == sav_out) { out = o; cnt = n; strong = false; }          // merged: the predecessor's state is as good as mine
+                else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; }    // back to the run guess
+            } else { out = o; cnt = n; }
+        }
         const uint64_t prev = seg_shfl_up1(out);
-        bool nd = false;
-        if (lane > 0u && j <= jl && prev != in) { in = prev; nd = walks; }
-        dirty = nd;
+        conflict = lane > 0u && j <= jl && prev != in;
+        const uint64_t closed = __ballot(!conflict);
+        const uint32_t first_open = ~closed ? (uint32_t)__builtin_ctzll(~closed) : 64u;
+        const bool pred_ver = lane0_true && lane <= first_open;
+        const bool pred_link = lane >= 2u ? ((closed >> (lane - 1u)) & 1ull) != 0ull : lane0_true;
+        const bool trusted = !strong || !walks || pred_ver || pred_link;
+        tent = false; dirty = false;
+        if (conflict && trusted) { in = prev; strong = false; dirty = walks; }
+        else if (conflict && prev != rej) { sav_in = in; sav_out = out; sav_cnt = cnt; in = prev; tent = true; dirty = true; }
     }
-    s_in[j] = in;
-    s_cnt[j] = walks ? cnt : 0u;
-    __hip_atomic_store(&s_out[j], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (links taken in the last round are closed once their lanes have walked; anything still open is reported)
+    const uint64_t prev = seg_shfl_up1(out);
+    const bool still_open = (lane > 0u && j <= jl && prev != in) || dirty;
+    const uint64_t any_open = __ballot(still_open);
+    st.in[j] = in;
+    st.cnt[j] = (walks ? cnt : 0u) | (strong ? 0x80000000u : 0u);
+    st.bnd[j] = B;
+    __hip_atomic_store(&st.out[j], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0u) st.open[k] = any_open ? 1u : 0u;
 }
 
-// Write pass of wave k: `base` = blocks in front of the lane's segment.
+// Write pass of wave k: `base` = blocks in front of the lane's segment, `end` = the next lane's boundary.
 __device__ __forceinline__ void seg_write(const SegCtx& c, uint32_t* __restrict__ win, uint32_t k, uint32_t jl, uint64_t in,
-                                          uint64_t next_in, uint32_t base, uint8_t* __restrict__ wf, uint64_t* __restrict__ tf,
-                                          uint32_t S_bytes, uint32_t* __restrict__ status) {
+                                          uint64_t next_in, uint32_t end, uint32_t base, uint8_t* __restrict__ wf,
+                                          uint64_t* __restrict__ tf, uint32_t S_bytes, uint32_t* __restrict__ status) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t j = 64u * k + lane;
     const bool part = j <= jl, last = j == jl;
     uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = base;
     bool bad = part && base > c.n_blocks;
-    seg_walk<true>(c, win, 64u * k, part && !bad, last ? 0xFFFFFFFFu : (j + 1u) * c.L, last, pos, w, n, wf, tf, bad);
+    seg_walk<true>(c, win, 64u * k, part && !bad, last ? 0xFFFFFFFFu : end, last, pos, w, n, wf, tf, bad);
     if (part && !last && seg_pack(pos, w) != next_in) bad = true;                       // the chain the counts came from
     if (last && !(n == c.n_blocks && pos <= c.limit && 1u + pos / 8u == S_bytes)) bad = true;   // S_f = 1 + bits/8 (Terse.hpp:547)
     if (__ballot(bad) && lane == 0u) atomicMax(&status[0], 5u);                         // TRPX_ERR_CORRUPT
@@ -252,110 +368,174 @@ __device__ __forceinline__ void seg_zero_widths(uint8_t* __restrict__ wf, uint32
     for (uint32_t i = lo + lane; i < hi; i += kWave) q[i] = z;
 }
 
-// ---- one wavefront per frame (G = 64): rounds, prefix sum and write pass in one launch ---------------------------------
-__global__ __launch_bounds__(kWave) void k_seg_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                      uint64_t* __restrict__ seg_in, uint64_t* __restrict__ seg_out,
-                                                      uint32_t* __restrict__ seg_cnt, uint8_t* __restrict__ widths,
-                                                      uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ only,
-                                                      uint32_t* __restrict__ status) {
-    __shared__ uint32_t win[kWave * kSegRow];
-    const uint64_t frame = blockIdx.x;
-    if (only && !only[frame]) return;                          // (frames the per-frame decoder kept for itself)
+struct SegWs {            // carve of seg_workspace_bytes()
+    uint64_t *in, *out;
+    uint32_t *cnt, *bnd, *base, *open, *fallback;
+};
+__host__ __device__ inline SegWs seg_carve(void* ws, size_t n_frames, uint32_t K) {
+    const size_t segs = n_frames * (size_t)K * kWave;
+    SegWs s;
+    s.in = reinterpret_cast<uint64_t*>(ws);
+    s.out = s.in + segs;
+    s.cnt = reinterpret_cast<uint32_t*>(s.out + segs);
+    s.bnd = s.cnt + segs;
+    s.base = s.bnd + segs;
+    s.open = s.base + segs;
+    s.fallback = s.open + n_frames * (size_t)K;
+    return s;
+}
+__device__ __forceinline__ SegState seg_state(const SegWs& w, uint64_t frame, uint32_t K) {
+    const uint64_t so = frame * K * kWave;
+    return SegState{w.in + so, w.out + so, w.cnt + so, w.bnd + so, w.base + so, w.open + frame * K};
+}
+
+// ---- one wavefront per frame (G = 64): rounds, prefix sum and write pass in one go ---------------------------------------
+__device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                               const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
+                                               const SegWs& ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                               uint64_t frame, uint32_t* __restrict__ win, uint32_t* __restrict__ status) {
     const uint32_t lane = (uint32_t)lane_id();
     SegCtx c;
-    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, kWave)) {
+    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, kWave, status)) {
         if (lane == 0) atomicMax(&status[0], 5u);
         return;
     }
     uint8_t* wf = widths + frame * g.n_blocks;
     uint64_t* tf = tile_off + frame * g.n_tiles;
     seg_zero_widths(wf, g.n_blocks, 0u, 1u);
-    uint64_t* s_in = seg_in + frame * kWave;
-    uint64_t* s_out = seg_out + frame * kWave;
-    uint32_t* s_cnt = seg_cnt + frame * kWave;
+    const SegState st = seg_state(ws, frame, 1u);
     const uint32_t jl = seg_last_live(c.limit, c.L, kWave);
-    seg_fixpoint(c, win, 0u, jl, true, false, s_in, s_out, s_cnt);
+    seg_fixpoint(c, win, 0u, jl, true, true, 70, st);
     __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before the write pass stores widths
-    const uint64_t in = s_in[lane];
-    const uint32_t cnt = s_cnt[lane];
+    const uint64_t in = st.in[lane];
+    const uint32_t cnt = st.cnt[lane] & 0x7FFFFFFFu;
     const uint64_t next_in = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)in, 1, 64) |
                              ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(in >> 32), 1, 64) << 32);
+    const uint32_t end = (uint32_t)__shfl_down((int)st.bnd[lane], 1, 64);
     const uint32_t base = wave_inclusive_scan(cnt) - cnt;
-    seg_write(c, win, 0u, jl, in, next_in, base, wf, tf, c.limit / 8u, status);
+    seg_write(c, win, 0u, jl, in, next_in, end, base, wf, tf, c.limit / 8u, status);
+}
+
+__global__ __launch_bounds__(kWave) void k_seg_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                      SegWs ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                      uint32_t* __restrict__ status) {
+    __shared__ uint32_t win[kWave * kSegRow];
+    seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, blockIdx.x, win, status);
+}
+
+// The frames k_decode_frames listed (list[0] = count, list[1 + i] = frame): one wavefront each, four to a workgroup (the
+// grid is launched for every frame of the stack and is normally empty: fewer, larger workgroups exit faster).
+__global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                         const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                         SegWs ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                         const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    __shared__ uint32_t win[4][kWave * kSegRow];
+    const uint32_t i = blockIdx.x * 4u + (uint32_t)wave_id();
+    if (i >= list[0]) return;
+    seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, list[1 + i], win[wave_id()], status);
+}
+
+// Tiles of the listed frames (the frames k_decode_frames gave up on -- its serial walker met an explicit header every
+// few blocks -- after k_seg_frames has walked them): a fixed grid strides over (listed frame, tile) pairs.
+template <typename T>
+__global__ __launch_bounds__(kThreads, 6) void k_unpack_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               const uint8_t* __restrict__ widths,
+                                                               const uint64_t* __restrict__ tile_off,
+                                                               const uint32_t* __restrict__ list, T* __restrict__ pixels_out,
+                                                               uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_image[unpack_image_dwords<T>()];
+    __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
+    const uint32_t count = list[0];
+    if (count == 0u || status[0] != 0u) return;
+    constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
+    const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
+    const uint64_t total = (uint64_t)count * tpf;
+    for (uint64_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const uint32_t frame = list[1 + (uint32_t)(i / tpf)];
+        if (!unpack_tile<T>(terse, terse_bytes, frame_offsets, g, frame, (uint32_t)(i % tpf), widths, tile_off, pixels_out, status,
+                            s_image, s_wtot))
+            return;
+        __syncthreads();
+    }
 }
 
 // ---- several wavefronts per frame (large frames): rounds / resolve / write are separate launches -------------------------
 __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                     uint32_t K, uint32_t first, uint64_t* __restrict__ seg_in,
-                                                     uint64_t* __restrict__ seg_out, uint32_t* __restrict__ seg_cnt,
-                                                     uint8_t* __restrict__ widths, uint32_t* __restrict__ status) {
+                                                     uint32_t K, uint32_t first, SegWs ws, uint8_t* __restrict__ widths,
+                                                     uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
     const uint64_t frame = blockIdx.x / K;
     const uint32_t k = blockIdx.x % K;
     SegCtx c;
-    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave)) {
+    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave, status)) {
         if (threadIdx.x == 0 && k == 0) atomicMax(&status[0], 5u);
         return;
     }
     if (first) seg_zero_widths(widths + frame * g.n_blocks, g.n_blocks, k, K);
     const uint32_t jl = seg_last_live(c.limit, c.L, K * kWave);
-    const uint64_t so = frame * K * kWave;
-    seg_fixpoint(c, win, k, jl, first != 0u, first == 0u, seg_in + so, seg_out + so, seg_cnt + so);
+    seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, 12, seg_state(ws, frame, K));
 }
 
-// One wavefront per frame: closes the links between the frame's waves that the rounds left open (serially, wave by
-// wave: each re-run starts from a verified state) and turns the block counts into block bases.
+// One wavefront per frame: closes the links the rounds left open -- between the frame's waves and inside them --
+// serially, wave by wave (each re-run starts from a verified state), and turns the block counts into block bases.
+// A frame with too many open waves is left to the serial walk (fallback flag).
 __global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                        const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                       uint32_t K, uint64_t* __restrict__ seg_in, uint64_t* __restrict__ seg_out,
-                                                       uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_base,
-                                                       uint32_t* __restrict__ status) {
+                                                       uint32_t K, SegWs ws, uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
     const uint64_t frame = blockIdx.x;
     const uint32_t lane = (uint32_t)lane_id();
+    if (lane == 0) ws.fallback[frame] = 0u;
     SegCtx c;
-    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave)) return;    // (reported by k_seg_round)
+    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave, status)) return;    // (reported by k_seg_round)
     const uint32_t jl = seg_last_live(c.limit, c.L, K * kWave);
-    const uint64_t so = frame * K * kWave;
-    uint32_t running = 0u;
-    for (uint32_t k = 0; k < K; ++k) {
-        if (k > 0u && 64u * k <= jl) {
-            const uint64_t a = __hip_atomic_load(&seg_in[so + 64u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t b = __hip_atomic_load(&seg_out[so + 64u * k - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a != b) {
-                seg_fixpoint(c, win, k, jl, false, true, seg_in + so, seg_out + so, seg_cnt + so);
-                __builtin_amdgcn_s_waitcnt(0);
-                __threadfence();
-            }
+    const SegState st = seg_state(ws, frame, K);
+    const uint32_t rerun_limit = 2u + K / 16u;
+    uint32_t running = 0u, reruns = 0u;
+    for (uint32_t k = 0; k < K && 64u * k <= jl; ++k) {
+        bool need = __hip_atomic_load(&st.open[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (k > 0u) {
+            const uint64_t a = __hip_atomic_load(&st.in[64u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t b = __hip_atomic_load(&st.out[64u * k - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            need = need || a != b;
         }
-        const uint32_t cnt = __hip_atomic_load(&seg_cnt[so + 64u * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need) {
+            if (++reruns > rerun_limit) {
+                if (lane == 0) ws.fallback[frame] = 1u;
+                return;
+            }
+            seg_fixpoint(c, win, k, jl, false, true, 70, st);
+            __builtin_amdgcn_s_waitcnt(0);
+            __threadfence();
+        }
+        const uint32_t cnt = __hip_atomic_load(&st.cnt[64u * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7FFFFFFFu;
         const uint32_t inc = wave_inclusive_scan(cnt);
-        seg_base[so + 64u * k + lane] = running + inc - cnt;
+        st.base[64u * k + lane] = running + inc - cnt;
         running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
 }
 
 __global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                     uint32_t K, const uint64_t* __restrict__ seg_in,
-                                                     const uint32_t* __restrict__ seg_base, uint8_t* __restrict__ widths,
+                                                     uint32_t K, SegWs ws, uint8_t* __restrict__ widths,
                                                      uint64_t* __restrict__ tile_off, uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
     const uint64_t frame = blockIdx.x / K;
     const uint32_t k = blockIdx.x % K;
     const uint32_t lane = (uint32_t)lane_id();
+    if (ws.fallback[frame]) return;                            // the serial walk does this frame
     SegCtx c;
-    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave)) return;
+    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave, status)) return;
     const uint32_t jl = seg_last_live(c.limit, c.L, K * kWave);
     if (64u * k > jl) return;
-    const uint64_t so = frame * K * kWave;
+    const SegState st = seg_state(ws, frame, K);
     const uint32_t j = 64u * k + lane;
-    const uint64_t in = seg_in[so + j];
-    const uint64_t next_in = j + 1u < K * kWave ? seg_in[so + j + 1u] : 0ull;
-    seg_write(c, win, k, jl, in, next_in, seg_base[so + j], widths + frame * g.n_blocks, tile_off + frame * g.n_tiles,
-              c.limit / 8u, status);
+    const bool has_next = j + 1u < K * kWave;
+    seg_write(c, win, k, jl, st.in[j], has_next ? st.in[j + 1u] : 0ull, has_next ? st.bnd[j + 1u] : 0xFFFFFFFFu, st.base[j],
+              widths + frame * g.n_blocks, tile_off + frame * g.n_tiles, c.limit / 8u, status);
 }
 
 // Segments per frame: a multiple of 64, about kSegTargetBlocks blocks each.
@@ -365,34 +545,60 @@ uint32_t seg_waves_per_frame(const FrameGeom& g) {
     return (uint32_t)(k ? k : 1);
 }
 size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames) {
-    const size_t segs = n_frames * (size_t)seg_waves_per_frame(g) * kWave;
-    return align_up(segs * (8 + 8 + 4 + 4), 256);
+    const size_t K = seg_waves_per_frame(g), segs = n_frames * K * kWave;
+    return align_up(segs * (8 + 8 + 4 + 4 + 4) + n_frames * K * 4 + n_frames * 4, 256);
 }
 
-// Fills a.widths / a.tile_off (the decode index) from the stream; `only` (device, u32 per frame, may be null) limits
-// the single-wave variant to the flagged frames.
-hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st) {
+hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st);   // decode_fast.hip
+
+// Fills a.widths / a.tile_off (the decode index) from the stream.
+hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
     const uint32_t K = seg_waves_per_frame(a.geom);
-    const size_t segs = (size_t)a.n_frames * K * kWave;
-    uint64_t* s_in = reinterpret_cast<uint64_t*>(a.seg_ws);
-    uint64_t* s_out = s_in + segs;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_out + segs);
-    uint32_t* s_base = s_cnt + segs;
+    const SegWs ws = seg_carve(a.seg_ws, a.n_frames, K);
     if (K == 1) {
         hipLaunchKernelGGL(k_seg_frames, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
-                           a.geom, max_w, s_in, s_out, s_cnt, a.widths, a.tile_off, only, a.status);
+                           a.geom, max_w, ws, a.widths, a.tile_off, a.status);
         return hipGetLastError();
     }
     const dim3 grid((uint32_t)((size_t)a.n_frames * K));
     hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, 1u, s_in, s_out, s_cnt, a.widths, a.status);
+                       K, 1u, ws, a.widths, a.status);
     hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, 0u, s_in, s_out, s_cnt, a.widths, a.status);
+                       K, 0u, ws, a.widths, a.status);
     hipLaunchKernelGGL(k_seg_resolve, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
-                       a.geom, max_w, K, s_in, s_out, s_cnt, s_base, a.status);
+                       a.geom, max_w, K, ws, a.status);
     hipLaunchKernelGGL(k_seg_write, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, s_in, s_base, a.widths, a.tile_off, a.status);
+                       K, ws, a.widths, a.tile_off, a.status);
+    return launch_walk_lds_only(a, max_w, ws.fallback, st);    // frames that did not converge: the serial walk
+}
+
+
+template <typename T>
+static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
+    const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
+    hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
+                       a.geom, (uint32_t)PixelTraits<T>::bits, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
+    constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
+    const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);
+    hipLaunchKernelGGL((k_unpack_listed<T>), dim3((uint32_t)(tiles < 1024 ? tiles : 1024)), dim3(kThreads), 0, st, a.terse,
+                       (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer),
+                       static_cast<T*>(a.pixels_out), a.status);
     return hipGetLastError();
+}
+
+bool seg_single_wave(const FrameGeom& g) { return seg_waves_per_frame(g) == 1; }
+
+// Decodes the frames flagged in a.defer (see k_decode_frames); needs seg_single_wave(a.geom).
+hipError_t launch_decode_deferred(int dtype, const DecodeArgs& a, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_decode_deferred_t<uint8_t>(a, st);
+    case 1: return launch_decode_deferred_t<int8_t>(a, st);
+    case 2: return launch_decode_deferred_t<uint16_t>(a, st);
+    case 3: return launch_decode_deferred_t<int16_t>(a, st);
+    case 4: return launch_decode_deferred_t<uint32_t>(a, st);
+    case 5: return launch_decode_deferred_t<int32_t>(a, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace trpx

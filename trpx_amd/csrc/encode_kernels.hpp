@@ -36,6 +36,7 @@ struct DecodeArgs {
     uint64_t*       tile_off;      // n_frames * n_tiles : bit offset of each tile inside its frame
     uint8_t*        widths;        // n_frames * n_blocks : significant bits of every block
     uint64_t*       walk_offsets;  // n_frames + 1 : frame offsets produced by the serial walk
+    uint32_t*       defer;         // 2 + n_frames words, 8-byte aligned (may be null): [0] = count, [1 + i] = frames the per-frame decoder hands to the position-parallel path
     void*           seg_ws;        // seg_workspace_bytes(): segment states of the position-parallel walk (decode_seg.hip)
 };
 
@@ -57,7 +58,10 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 // position-parallel header walk (decode_seg.hip): fills a.widths / a.tile_off like launch_walk_only; needs a.seg_ws
 size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames);
-hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st);
+hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
+// frames k_decode_frames flagged in a.defer (explicit headers every few blocks): position-parallel walk + tiled extraction
+bool seg_single_wave(const FrameGeom& g);
+hipError_t launch_decode_deferred(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_synth(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
                         void* out, hipStream_t st);
 
