@@ -29,6 +29,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    # both sides of the step carry a roofline block (the dominant one under `roofline`), and the legs the headline
+    # data hides are reported: index-free decode of the 4096x4096 frames, the header-dense noisy stack
+    other = [k for k in ("roofline_encode", "roofline_decode") if k in b]
+    assert len(other) == 1 and b[other[0]]["avg_launch_ms"] <= rf["avg_launch_ms"]
+    assert "decode_fps" in b["config3_4096x4096_int32"] and "roofline_encode" in b["config3_4096x4096_int32"], b["config3_4096x4096_int32"]
+    assert b["noisy_u16"].get("roundtrip_exact") is True and b["noisy_u16"]["decode_fps"] > 0, b["noisy_u16"]
+    assert "byte-identical" in b["oracle_check"]
     cb = b["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
