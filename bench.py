@@ -140,7 +140,8 @@ def main():
 
     # The per-frame size gather (RCCL over xGMI -> global byte offset of every frame) depends only on the encode and
     # nothing in the decode depends on it: it runs on its own stream next to the decode and is joined at the step's end.
-    gather = sharded.SizeGather(frames, dev) if use_dist else None
+    # (C ABI: trpx_gather_frame_offsets = pack kernel + ncclAllGather + scan kernel on the communicator below)
+    gather = sharded.RcclSizeGather(frames, dev) if use_dist else None
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     def step():
@@ -149,7 +150,7 @@ def main():
             cur = torch.cuda.current_stream()
             comm_stream.wait_stream(cur)
             with torch.cuda.stream(comm_stream):
-                gather(offs, st_e[1:2])
+                gather(offs, st_e)
         # decode straight from the device-resident stack (bounded by its worst-case capacity; the
         # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
         codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
@@ -181,6 +182,11 @@ def main():
     total_bytes = int(offs[-1].item())
     if rank == 0 and frames == FRAMES_PER_GPU:
         assert total_bytes == 203596114, "stack size differs from the reference's (SURVEY.md 8 row d)"
+    if use_dist:                                             # what the step's gather computed: this rank's place in the global stack
+        goffs, gbase, gpb = gather(offs, st_e)
+        torch.cuda.synchronize()
+        assert int(goffs[rank * frames + frames] - goffs[rank * frames]) == total_bytes and int(gbase) == int(goffs[rank * frames])
+        assert int(gpb) >= int(st_e[1].item())
 
     # ---- the encoded stack against the CPU oracle (a sample of what was just timed; rank 0) ----
     oracle_check = None
@@ -373,6 +379,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(px.cpu().numpy(), cores)
         print(json.dumps(result))
     if use_dist:
+        gather.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -225,6 +225,30 @@ int trpx_header_parse(const char* data, size_t len, trpx_header* h, size_t* payl
 size_t trpx_header_format_indexed(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, char* buf, size_t buf_cap);
 size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity);
 
+/* ---- multi-GPU (SURVEY.md section 8 row e): frames shard across GPUs, one process per GPU ----------------------
+ * A frame's stream does not depend on its neighbours -- the header state resets per frame and every frame starts byte
+ * aligned (Terse.hpp:502-505, :359) -- so rank r encodes its contiguous frame range with trpx_encode and keeps its
+ * bytes.  What the serial encoder's cursor (Terse.hpp:502-504) would have been for the WHOLE stack is recovered by
+ * the one collective of the path: trpx_gather_frame_offsets all-gathers the per-frame sizes (S_f, Terse.hpp:547) of
+ * every rank over RCCL / xGMI (ncclAllGather, 8 bytes per frame) on `stream` and writes
+ *   global_offsets[0 .. F_total]  byte offset of every frame of the global stack (ranks in order) + its total size,
+ *   *prolix_bits                  maximum over the ranks' d_prolix_bits (Terse.hpp:516; encode_status = the status
+ *                                 block trpx_encode filled, may be NULL), may be NULL,
+ *   rank_base[0 .. world)         first byte of every rank's local stack inside the global one, may be NULL.
+ * comm is an ncclComm_t of the caller (or one made by trpx_comm_init); n_slot >= every rank's n_local is the common
+ * message size (shards may be ragged); all pointers are device pointers; stream-ordered, no host sync, no allocation.
+ * The payload never crosses xGMI.  RCCL is resolved at run time (TRPX_ERR_UNSUPPORTED without it). */
+size_t trpx_gather_workspace_bytes(size_t n_slot, int world);
+int trpx_gather_frame_offsets(void* comm, const uint64_t* local_offsets, size_t n_local, size_t n_slot,
+                              const uint32_t* encode_status, uint64_t* global_offsets, uint32_t* prolix_bits,
+                              uint64_t* rank_base, void* workspace, size_t workspace_bytes, void* stream);
+/* A communicator for callers that have none: rank 0 makes the 128-byte id, every rank gets it by its own means
+ * (MPI, torch.distributed, a file) and calls trpx_comm_init with the GPU it will use already selected. */
+int trpx_comm_unique_id(void* id128);
+int trpx_comm_init(void** comm, int world, int rank, const void* id128);
+int trpx_comm_destroy(void* comm);
+const char* trpx_shard_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

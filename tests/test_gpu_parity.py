@@ -627,3 +627,42 @@ def test_width_changes_every_block_position_parallel_walk(gpu, oracle, dtype):
         for name, idx in (("encoder", enc.index), ("walk", walked)):
             got_w = idx[w_off: w_off + frames * nblk].cpu().numpy().reshape(frames, nblk)
             assert (got_w == want_w).all(), (dtype, frames, name)
+
+
+def test_sharded_c_abi_size_gather_over_rccl(gpu, oracle):
+    """SURVEY row e through the C ABI: HIP encode of this rank's shard -> trpx_gather_frame_offsets (pack kernel,
+    ncclAllGather on a real RCCL communicator -- one rank here, the N > 1 logic runs under gloo in tests/test_sharded.py --
+    scan kernel) -> the shard written at its global byte offset -> decode with the GLOBAL offsets == the pixels, and the
+    assembled stack == the oracle's single-process stack (Terse.hpp:502-505: frames are independent, byte aligned)."""
+    import torch
+    from trpx_amd import codec, sharded
+    frames, n = 37, 64 * 64
+    px = codec.synth(np.uint16, 5, frames, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    g = sharded.RcclSizeGather(frames, gpu)
+    try:
+        for _ in range(2):                                              # buffers and communicator are reused call after call
+            goffs, base, pb = g(enc.frame_offsets, enc.status)
+        torch.cuda.synchronize()
+        assert torch.equal(goffs, enc.frame_offsets) and int(base) == 0 and int(pb) == enc.prolix_bits()
+        want, sizes, opb = oracle.encode_stack(px.cpu().numpy())
+        assert int(goffs[-1]) == want.size and opb == int(pb)
+        global_stack = torch.zeros((want.size + 15) // 16 * 16, dtype=torch.uint8, device=gpu)
+        global_stack[int(base): int(base) + enc.total_bytes()] = enc.stack()        # payload stays on its GPU, at its global offset
+        assert global_stack[: want.size].cpu().numpy().tobytes() == want.tobytes()
+        back, st = codec.decode(global_stack, goffs, n, frames, np.uint16)
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
+        # ragged message: a slot larger than the shard (n_slot > n_local), as unequal shards use it
+        from trpx_amd import _lib
+        L = _lib.lib()
+        ws = torch.empty(L.trpx_gather_workspace_bytes(frames + 11, 1), dtype=torch.uint8, device=gpu)
+        g2 = torch.zeros(frames + 12, dtype=torch.int64, device=gpu)
+        rc = L.trpx_gather_frame_offsets(g.comm, enc.frame_offsets.data_ptr(), frames, frames + 11, None, g2.data_ptr(), None, None,
+                                         ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.equal(g2[: frames + 1], enc.frame_offsets)
+    finally:
+        g.close()

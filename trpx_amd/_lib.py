@@ -50,6 +50,12 @@ SYMBOLS = {
     "trpx_encode_host": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, C.POINTER(_SZ), _P, C.POINTER(_U), _I]),
     "trpx_decode_host": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _I]),
     "trpx_frame_offsets_host": (_I, [_P, _SZ, _SZ, _SZ, _U, _U, _P, _I]),
+    "trpx_gather_workspace_bytes": (_SZ, [_SZ, _I]),
+    "trpx_gather_frame_offsets": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P, _SZ, _P]),
+    "trpx_comm_unique_id": (_I, [_P]),
+    "trpx_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
+    "trpx_comm_destroy": (_I, [_P]),
+    "trpx_shard_last_error": (C.c_char_p, []),
     "trpx_set_encode_path": (_I, [_I]),
     "trpx_profile_enable": (_I, [_I]),
     "trpx_profile_read": (_I, [C.POINTER(C.c_float), _I]),

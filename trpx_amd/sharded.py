@@ -79,3 +79,59 @@ class SizeGather:
         g = self.gathered.view(self.world, self.f + 1)
         torch.cumsum(g[:, : self.f].reshape(-1), 0, out=self.global_offsets[1:])
         return self.global_offsets, self.global_offsets[self.rank * self.f], g[:, self.f].max()
+
+
+class RcclSizeGather:
+    """The size gather through the C ABI (`trpx_gather_frame_offsets`, include/trpx_hip.h): one pack kernel, one
+    ncclAllGather on the calling stream, one scan kernel -- what a C++ `jpa::Terse`-style caller uses.  The RCCL
+    communicator is made here from an id that rank 0 creates and torch.distributed carries to the other ranks (any
+    transport would do); with no process group it is a one-rank communicator.  GPU only."""
+
+    def __init__(self, frames_per_rank: int, device, group=None):
+        import ctypes as C
+        from . import _lib
+        self._L = _lib.lib()
+        self._lib = _lib
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.f = int(frames_per_rank)
+        device = torch.device(device)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            self._check(self._L.trpx_comm_unique_id(C.cast(buf, C.c_void_p)))
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world > 1:
+            on = ident.to(device) if dist.get_backend(group) == "nccl" else ident
+            dist.broadcast(on, src=0, group=group)
+            ident = on.cpu()
+        raw = bytes(ident.numpy().tobytes())
+        comm = C.c_void_p()
+        with torch.cuda.device(device):
+            self._check(self._L.trpx_comm_init(C.byref(comm), self.world, self.rank, raw))
+        self.comm = comm
+        self.global_offsets = torch.zeros(self.world * self.f + 1, dtype=torch.int64, device=device)
+        self.prolix = torch.zeros(2, dtype=torch.int32, device=device)
+        self.rank_base = torch.zeros(self.world, dtype=torch.int64, device=device)
+        self.ws = torch.empty(self._L.trpx_gather_workspace_bytes(self.f, self.world), dtype=torch.uint8, device=device)
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise self._lib.TrpxError(rc, self._L.trpx_shard_last_error().decode(errors="replace"))
+
+    def __call__(self, local_offsets: torch.Tensor, encode_status: torch.Tensor | None = None):
+        """local_offsets: int64 [f + 1] on the GPU (what trpx_encode wrote); encode_status: the encode's status block
+        (word 1 = prolix_bits) or None.  Returns (global_offsets, my_base, prolix_bits) as views of internal buffers;
+        stream-ordered on the current stream."""
+        assert local_offsets.is_cuda and local_offsets.numel() == self.f + 1 and local_offsets.dtype == torch.int64
+        st = torch.cuda.current_stream(local_offsets.device).cuda_stream
+        self._check(self._L.trpx_gather_frame_offsets(self.comm, local_offsets.data_ptr(), self.f, self.f,
+                                                      encode_status.data_ptr() if encode_status is not None else None,
+                                                      self.global_offsets.data_ptr(), self.prolix.data_ptr(),
+                                                      self.rank_base.data_ptr(), self.ws.data_ptr(), self.ws.numel(), st))
+        return self.global_offsets, self.rank_base[self.rank], self.prolix[0]
+
+    def close(self) -> None:
+        if self.comm:
+            self._L.trpx_comm_destroy(self.comm)
+            self.comm = None
