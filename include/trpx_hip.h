@@ -183,6 +183,19 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
 int trpx_set_encode_path(int path);
 
 /*
+ * trpx_encode_indexed + the one thing a stream-ordered call cannot do for itself: it waits for `stream`, reads the
+ * status block and, if a look-back wait of the single-pass encoder gave up (TRPX_ERR_TIMEOUT: tiles wait for earlier
+ * tiles of the same launch -- bounded to 0.25 s of wall time, never seen with in-order workgroup dispatch, but the
+ * hardware does not promise it), runs the call again through the two-pass pipeline, which has no inter-tile waits and
+ * writes the identical stream (f_compress is deterministic, Terse.hpp:500-549).  Returns the final status as its
+ * return value (TRPX_OK = stack complete) and, if host_status is not NULL, the 8 status words.  `index` may be NULL.
+ * Callers that stay asynchronous use trpx_encode and apply the same rule when they read the status block.
+ */
+int trpx_encode_checked(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
+                        size_t out_capacity, uint64_t* frame_offsets, uint32_t* status, void* index, void* workspace,
+                        size_t workspace_bytes, void* stream, uint32_t* host_status);
+
+/*
  * Per-kernel timing for bench.py's roofline leg.  While enabled (per calling thread), trpx_encode /
  * trpx_decode record a hipEvent on `stream` before their first and after each of their kernels;
  * trpx_profile_read waits for the last launch and returns the elapsed ms of each stage
@@ -242,6 +255,13 @@ size_t trpx_gather_workspace_bytes(size_t n_slot, int world);
 int trpx_gather_frame_offsets(void* comm, const uint64_t* local_offsets, size_t n_local, size_t n_slot,
                               const uint32_t* encode_status, uint64_t* global_offsets, uint32_t* prolix_bits,
                               uint64_t* rank_base, void* workspace, size_t workspace_bytes, void* stream);
+/* The two kernels of that call for callers that move the messages themselves (MPI, a host gather): trpx_gather_pack
+ * writes this rank's message, u64[n_slot + 2] = { S_0 .. S_{n_local-1}, 0 .., n_local, prolix_bits }; trpx_gather_scan
+ * turns the `world` messages, concatenated in rank order, into global_offsets / prolix_bits / rank_base as above. */
+int trpx_gather_pack(const uint64_t* local_offsets, size_t n_local, size_t n_slot, const uint32_t* encode_status, uint64_t* message,
+                     void* stream);
+int trpx_gather_scan(const uint64_t* all_messages, int world, size_t n_slot, uint64_t* global_offsets, uint32_t* prolix_bits,
+                     uint64_t* rank_base, void* stream);
 /* A communicator for callers that have none: rank 0 makes the 128-byte id, every rank gets it by its own means
  * (MPI, torch.distributed, a file) and calls trpx_comm_init with the GPU it will use already selected. */
 int trpx_comm_unique_id(void* id128);

@@ -664,5 +664,69 @@ def test_sharded_c_abi_size_gather_over_rccl(gpu, oracle):
                                          ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert rc == 0 and torch.equal(g2[: frames + 1], enc.frame_offsets)
+        # the N > 1 arithmetic of the two kernels, ranks emulated on this GPU: three ragged shards (one empty), 700-frame
+        # slot (several scan chunks), messages concatenated in rank order as ncclAllGather leaves them
+        rng = np.random.RandomState(4)
+        counts, slot = [700, 0, 333], 700
+        sizes = [rng.randint(1, 200000, size=c).astype(np.int64) for c in counts]
+        msgs = torch.zeros(3 * (slot + 2), dtype=torch.int64, device=gpu)
+        st_words = torch.zeros(8, dtype=torch.int32, device=gpu)
+        for r, sz in enumerate(sizes):
+            lo = torch.from_numpy(np.concatenate([[0], np.cumsum(sz)])).to(gpu)
+            st_words[1] = 5 + 3 * r
+            assert L.trpx_gather_pack(lo.data_ptr(), counts[r], slot, st_words.data_ptr(), msgs[r * (slot + 2):].data_ptr(), None) == 0
+            torch.cuda.synchronize()
+        go = torch.zeros(sum(counts) + 1, dtype=torch.int64, device=gpu)
+        pbw = torch.zeros(2, dtype=torch.int32, device=gpu)
+        rb = torch.zeros(3, dtype=torch.int64, device=gpu)
+        assert L.trpx_gather_scan(msgs.data_ptr(), 3, slot, go.data_ptr(), pbw.data_ptr(), rb.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        want_go = np.concatenate([[0], np.cumsum(np.concatenate(sizes))])
+        assert (go.cpu().numpy() == want_go).all() and int(pbw[0]) == 11
+        assert rb.cpu().numpy().tolist() == [0, int(want_go[700]), int(want_go[700])]
     finally:
         g.close()
+
+
+def test_lookback_timeout_falls_back_to_two_pass(gpu, oracle, tmp_path):
+    """A look-back wait of the single-pass encoder that gives up (TRPX_ERR_TIMEOUT) must not cost the caller the stack:
+    in a test build of the library whose waits give up at once (make force_timeout: -DTRPX_FORCE_TIMEOUT) the plain
+    stream-ordered call reports status 7, and trpx_encode_checked / Encoded.check() / trpx_encode_host end with status 0
+    and the oracle's bytes (re-run through the two-pass pipeline)."""
+    variant = os.path.join(ROOT, "tools", "variants", "libtrpx_force_timeout.so")
+    if not os.path.exists(variant):
+        pytest.skip("test variant not built (make -C trpx_amd/csrc force_timeout)")
+    script = tmp_path / "t.py"
+    script.write_text(f"""
+import sys, ctypes as C
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from trpx_amd import codec, _lib
+from oracle import oracle as O
+L = _lib.lib()
+frames, n = 40, 512 * 512
+px = codec.synth(np.uint16, 0, frames, n)
+want, sizes, pb = O.encode_stack(px.cpu().numpy())
+enc = codec.encode(px)
+torch.cuda.synchronize()
+assert int(enc.status[0]) == _lib.ERR_TIMEOUT, int(enc.status[0])       # the forced failure is really there
+enc.check()                                                              # re-runs through trpx_encode_checked
+assert int(enc.status[0]) == 0 and enc.prolix_bits() == pb
+assert enc.stack().cpu().numpy().tobytes() == want.tobytes()
+host = np.zeros(8, np.uint32)
+ws = codec.Workspace("cuda")
+enc2 = codec.encode(px, workspace=ws)
+torch.cuda.synchronize()
+w = ws.buf
+rc = L.trpx_encode_checked(_lib.U16, px.data_ptr(), n, frames, 12, enc2.data.data_ptr(), enc2.data.numel(), enc2.frame_offsets.data_ptr(),
+                           enc2.status.data_ptr(), None, w.data_ptr(), w.numel(), None, host.ctypes.data)
+assert rc == 0 and host[0] == 0 and host[1] == pb and enc2.stack().cpu().numpy().tobytes() == want.tobytes()
+out = np.zeros(want.size + 64, np.uint8); total = C.c_size_t(0); gpb = C.c_uint(0); offs = np.zeros(frames + 1, np.uint64)
+hp = px.cpu().numpy()
+_lib.check(L.trpx_encode_host(_lib.U16, hp.ctypes.data, n, frames, 12, out.ctypes.data, out.size, C.byref(total), offs.ctypes.data, C.byref(gpb), -1))
+assert total.value == want.size and (out[: want.size] == want).all() and gpb.value == pb
+print("OK")
+""")
+    env = dict(os.environ, TRPX_LIB=variant)
+    r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

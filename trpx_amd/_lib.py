@@ -44,6 +44,7 @@ SYMBOLS = {
     "trpx_decode": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P, _SZ, _P]),
     "trpx_index_bytes": (_SZ, [_I, _SZ, _SZ, _U]),
     "trpx_encode_indexed": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
+    "trpx_encode_checked": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _P, _SZ, _P, _P]),
     "trpx_build_index": (_I, [_I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P]),
     "trpx_decode_indexed": (_I, [_I, _I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _P, _P, _P]),
     "trpx_decode_convert": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P, _SZ, _P]),
@@ -52,6 +53,8 @@ SYMBOLS = {
     "trpx_frame_offsets_host": (_I, [_P, _SZ, _SZ, _SZ, _U, _U, _P, _I]),
     "trpx_gather_workspace_bytes": (_SZ, [_SZ, _I]),
     "trpx_gather_frame_offsets": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P, _SZ, _P]),
+    "trpx_gather_pack": (_I, [_P, _SZ, _SZ, _P, _P, _P]),
+    "trpx_gather_scan": (_I, [_P, _I, _SZ, _P, _P, _P, _P]),
     "trpx_comm_unique_id": (_I, [_P]),
     "trpx_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
     "trpx_comm_destroy": (_I, [_P]),

@@ -47,6 +47,7 @@ class Encoded:
     n_frames: int
     dtype: torch.dtype
     index: torch.Tensor | None = None   # optional decode index (trpx_encode_indexed)
+    _retry: tuple | None = None         # what check() needs to run the call again (see check)
 
     def total_bytes(self) -> int:
         return int(self.frame_offsets[-1].item())
@@ -55,7 +56,18 @@ class Encoded:
         return int(self.status[1].item())
 
     def check(self) -> None:
+        """Synchronises and raises on a device error.  A look-back timeout of the single-pass encoder (TRPX_ERR_TIMEOUT,
+        see trpx_encode_checked in include/trpx_hip.h) is not an error of the data: the call is run again through the
+        two-pass pipeline (trpx_encode_checked), which writes the identical stream."""
         code = int(self.status[0].item())
+        if code == _lib.ERR_TIMEOUT and self._retry is not None:
+            px, ws, block = self._retry
+            with torch.cuda.device(px.device):
+                check(lib().trpx_encode_checked(dtype_code(px.dtype), px.data_ptr(), self.n_values, self.n_frames, block,
+                                                self.data.data_ptr(), self.data.numel(), self.frame_offsets.data_ptr(),
+                                                self.status.data_ptr(), self.index.data_ptr() if self.index is not None else None,
+                                                ws.data_ptr(), ws.numel(), _stream_ptr(px), None))
+            code = int(self.status[0].item())
         if code:
             raise _lib.TrpxError(code, "device status after encode")
 
@@ -109,7 +121,7 @@ def encode(pixels: torch.Tensor, out: torch.Tensor | None = None, workspace: Wor
                                         frame_offsets.data_ptr(), status.data_ptr(),
                                         index.data_ptr() if index is not None else None, ws.data_ptr(), ws.numel(),
                                         _stream_ptr(px)))
-    return Encoded(out, frame_offsets, status, n_values, n_frames, px.dtype, index if index is not None else None)
+    return Encoded(out, frame_offsets, status, n_values, n_frames, px.dtype, index if index is not None else None, (px, ws, block))
 
 
 def decode(terse: torch.Tensor, frame_offsets: torch.Tensor | None, n_values: int, n_frames: int, dtype,

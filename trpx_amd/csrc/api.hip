@@ -200,6 +200,25 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     return TRPX_OK;
 }
 
+int trpx_encode_checked(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
+                        size_t out_capacity, uint64_t* frame_offsets, uint32_t* status, void* index, void* workspace,
+                        size_t workspace_bytes, void* stream, uint32_t* host_status) {
+    uint32_t st[TRPX_STATUS_WORDS] = {0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        t_force_two_pass = attempt == 1;                     // (this thread's next call only)
+        const int rc = trpx_encode_indexed(dtype, pixels, n_values, n_frames, block, out, out_capacity, frame_offsets, status,
+                                           index, workspace, workspace_bytes, stream);
+        t_force_two_pass = false;
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        HIP_TRY(hipMemcpy(st, status, sizeof st, hipMemcpyDeviceToHost));
+        if (st[0] != TRPX_ERR_TIMEOUT) break;                // a look-back wait gave up: the two-pass pipeline has no waits
+    }
+    if (host_status) memcpy(host_status, st, sizeof st);
+    if (st[0]) return fail((int)st[0], "trpx_encode_checked: device status %u", st[0]);
+    return TRPX_OK;
+}
+
 int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
                 const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
                 uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {

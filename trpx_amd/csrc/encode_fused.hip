@@ -38,7 +38,25 @@ namespace trpx {
 // 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
 template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
 template <typename T> constexpr int fused_occupancy() { return sizeof(T) <= 2 ? 6 : 4; }   // workgroups per CU (LDS image + VGPR budget)
-constexpr uint32_t kSpinLimit = 1u << 22;                // bounded waits (~seconds), then give up
+// Every wait on another tile is bounded in WALL time: a poll loop gives up kWaitTicks of the 100 MHz realtime counter
+// after it started (0.25 s; the whole 2000-frame launch takes 0.3 ms, so this only ever triggers when tiles do not
+// make progress at all), checked every 64 polls.  The caller then sees TRPX_ERR_TIMEOUT in status[0]
+// (trpx_encode_checked / the host wrappers re-run through the two-pass pipeline).
+[[maybe_unused]] constexpr uint64_t kWaitTicks = 25u * 1000u * 1000u;
+struct SpinGuard {
+    uint64_t t0 = 0;
+    uint32_t spins = 0;
+    __device__ __forceinline__ bool expired() {
+#ifdef TRPX_FORCE_TIMEOUT
+        return true;                                     // test build: every wait that does not succeed at once gives up
+#else
+        if ((++spins & 63u) != 0u) return false;
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) { t0 = now; return false; }
+        return now - t0 > kWaitTicks;
+#endif
+    }
+};
 
 // Diagnostics (tools/stamps.py, tools/enc_time.py): only in builds with -DTRPX_DIAGNOSTICS; the product build folds
 // every `diag(a) & x` test to false.  Bits: 1 = skip the look-back waits, 2 = skip the tail wait (both give WRONG
@@ -86,7 +104,7 @@ __device__ bool lookback(const uint64_t* __restrict__ desc, int64_t idx, int64_t
         const bool in = my >= lo;
         uint64_t g = in ? 0ull : make_desc(kStPrefix, 0);                // below `lo`: prefix 0 ends the chain
         uint32_t first_p = 64;
-        uint32_t spins = 0;
+        SpinGuard guard;
         uint64_t need = ~0ull;
         for (;;) {
             // re-read only what is still missing AND still matters (lanes behind the nearest prefix never do): the polls
@@ -97,7 +115,7 @@ __device__ bool lookback(const uint64_t* __restrict__ desc, int64_t idx, int64_t
             first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
             need = first_p >= 63u ? ~0ull : ((2ull << first_p) - 1ull);
             if ((imask & need) == 0) break;
-            if (++spins > kSpinLimit) return false;
+            if (guard.expired()) return false;
             __builtin_amdgcn_s_sleep(2);
         }
         acc += wave_sum64((uint32_t)lane <= first_p ? desc_value(g) : 0ull);
@@ -124,7 +142,8 @@ __device__ bool lookback_frames(const uint64_t* __restrict__ acc_w, const uint64
         const int64_t my = pos - lane;
         const bool in = my >= 0;
         uint64_t p = in ? 0ull : kPrefFlag, c = 0;                       // below frame 0: prefix 0 ends the chain
-        uint32_t first_p = 64, spins = 0;
+        uint32_t first_p = 64;
+        SpinGuard guard;
         uint64_t need = ~0ull;
         bool complete = false;
         for (;;) {
@@ -139,7 +158,7 @@ __device__ bool lookback_frames(const uint64_t* __restrict__ acc_w, const uint64
             first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
             need = first_p >= 64u ? ~0ull : ((1ull << first_p) - 1ull);  // the lanes in front of the prefix
             if ((~cmask & need) == 0) break;
-            if (++spins > kSpinLimit) return false;
+            if (guard.expired()) return false;
             __builtin_amdgcn_s_sleep(2);
         }
         const uint64_t mine = (uint32_t)lane < first_p ? 1 + (c & ((1ull << kAccShift) - 1)) / 8
@@ -580,11 +599,11 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
                 if (ok && lane == 0) st_desc(a.frame_base + (uint64_t)frame * 16, kPrefFlag | base);
             } else {
                 uint64_t vb = 0;
-                uint32_t spins = 0;
+                SpinGuard guard;
                 for (;;) {
                     vb = ld_desc(a.frame_base + (uint64_t)frame * 16);   // same address in every lane: one request
                     if (vb & kPrefFlag) break;
-                    if (++spins > kSpinLimit) { ok = false; break; }
+                    if (guard.expired()) { ok = false; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 base = vb & ~kPrefFlag;

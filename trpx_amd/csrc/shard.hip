@@ -85,6 +85,7 @@ __global__ __launch_bounds__(trpx::kThreads) void k_gather_pack(const uint64_t* 
 __global__ __launch_bounds__(trpx::kThreads) void k_gather_scan(const uint64_t* __restrict__ all, uint32_t world, uint32_t n_slot,
                                                                uint64_t* __restrict__ global_offsets, uint32_t* __restrict__ prolix_bits,
                                                                uint64_t* __restrict__ rank_base) {
+    // (rank_base may be null)
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -159,6 +160,26 @@ int trpx_gather_frame_offsets(void* comm, const uint64_t* local_offsets, size_t 
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return shard_fail(TRPX_ERR_HIP, "trpx_gather_frame_offsets", hipGetErrorString(e));
     return TRPX_OK;
+}
+
+int trpx_gather_pack(const uint64_t* local_offsets, size_t n_local, size_t n_slot, const uint32_t* encode_status, uint64_t* message,
+                     void* stream) {
+    if (!local_offsets || !message || n_local > n_slot || n_slot == 0 || n_slot > 0x7FFFFFF0ull)
+        return shard_fail(TRPX_ERR_INVALID_ARG, "trpx_gather_pack", "bad argument");
+    hipLaunchKernelGGL(k_gather_pack, dim3((unsigned)((n_slot + 2 + trpx::kThreads - 1) / trpx::kThreads)), dim3(trpx::kThreads), 0,
+                       static_cast<hipStream_t>(stream), local_offsets, (uint32_t)n_local, (uint32_t)n_slot, encode_status, message);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRPX_OK : shard_fail(TRPX_ERR_HIP, "trpx_gather_pack", hipGetErrorString(e));
+}
+
+int trpx_gather_scan(const uint64_t* all_messages, int world, size_t n_slot, uint64_t* global_offsets, uint32_t* prolix_bits,
+                     uint64_t* rank_base, void* stream) {
+    if (!all_messages || !global_offsets || world <= 0 || n_slot == 0 || n_slot > 0x7FFFFFF0ull)
+        return shard_fail(TRPX_ERR_INVALID_ARG, "trpx_gather_scan", "bad argument");
+    hipLaunchKernelGGL(k_gather_scan, dim3(1), dim3(trpx::kThreads), 0, static_cast<hipStream_t>(stream), all_messages, (uint32_t)world,
+                       (uint32_t)n_slot, global_offsets, prolix_bits, rank_base);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRPX_OK : shard_fail(TRPX_ERR_HIP, "trpx_gather_scan", hipGetErrorString(e));
 }
 
 int trpx_comm_unique_id(void* id128) {
