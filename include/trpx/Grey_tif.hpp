@@ -130,8 +130,9 @@ private:
         return get32(at);
     }
     std::vector<std::uint32_t> entry_array(std::size_t at, unsigned type, std::uint32_t count) const {
-        std::vector<std::uint32_t> v(count);
         const unsigned esz = (type == 3 || type == 8) ? 2 : 4;
+        if (count > d_tif.size() / esz) throw std::runtime_error("corrupt TIFF file: array longer than the file");   // before allocating
+        std::vector<std::uint32_t> v(count);
         const std::size_t src = (std::size_t)count * esz <= 4 ? at : get32(at);
         for (std::uint32_t i = 0; i < count; ++i) v[i] = esz == 2 ? get16(src + 2 * (std::size_t)i) : get32(src + 4 * (std::size_t)i);
         return v;
@@ -173,6 +174,8 @@ private:
                     throw std::runtime_error("Incompatible TIFF file: non-consecutive strips");
             img.bytes_per_pixel = bits / 8;
             img.offset = strip_off[0];
+            if (img.pixels() > d_tif.size() / img.bytes_per_pixel)                  // (a product could wrap: 2^31 x 2^30 x 8 bytes = 2^64)
+                throw std::runtime_error("corrupt TIFF file: image larger than the file");
             need(img.offset, img.pixels() * img.bytes_per_pixel);
             if (d_swap && img.bytes_per_pixel > 1) {             // pixels to host byte order, in place
                 std::uint8_t* p = d_tif.data() + img.offset;

@@ -247,6 +247,15 @@ private:
             if (trpx_header_parse(blob.data(), got, &h, &off) == TRPX_OK) break;
             if (got < want || want >= (std::size_t(1) << 28)) throw std::invalid_argument("no valid <Terse .../> header");
         }
+        // nothing of the header is believed before it is checked against the file: every frame is at least one byte
+        // (Terse.hpp:547), the payload cannot be longer than what follows the header
+        istream.seekg(0, std::ios::end);
+        const std::streamoff file_end = istream.tellg();
+        istream.clear();
+        const std::uint64_t avail = file_end >= std::streamoff(pos) + std::streamoff(off) ? std::uint64_t(file_end - std::streamoff(pos) - std::streamoff(off)) : 0;
+        if (h.memory_size > avail) throw std::runtime_error("truncated .trpx payload");
+        if (h.number_of_frames > h.memory_size || h.number_of_values == 0 || h.block == 0 || h.block > 4096 || h.prolix_bits > 64)
+            throw std::invalid_argument("inconsistent <Terse .../> header");
         d_prolix_bits = h.prolix_bits;
         d_signed = h.is_signed;
         d_block = h.block;

@@ -110,3 +110,21 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_UNSUPPORTED
     rc = L.trpx_encode(2, 16, 100, 1, 12, 16, 0, 16, 16, 16, 8, None)                # workspace too small
     assert rc == _lib.ERR_CAPACITY
+
+
+def test_host_code_survives_corrupt_input_under_asan_ubsan(tmp_path):
+    """SURVEY section 5 (sanitizers on host code): tests/cpp/host_sanitize.cpp drives everything in the product that
+    parses untrusted bytes on the host -- the .trpx header text (header_text.cpp), the TIFF reader (Grey_tif.hpp scan:
+    including the size_t-overflow image and the 2^32-entry array of ADVICE r1) and Terse(std::ifstream&) (Terse.hpp
+    f_read) -- with valid, truncated and randomly corrupted inputs in a g++ -fsanitize=address,undefined build (CPU only)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp"), "host_sanitize"])
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    path = os.path.join(scratch, f"trpx_host_sanitize_{os.getpid()}.trpx")
+    try:
+        r = subprocess.run([os.path.join(root, "tests", "cpp", "host_sanitize"), path], capture_output=True, text=True, timeout=300)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    assert r.returncode == 0 and "OK host_sanitize" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -50,6 +50,14 @@ bool geom_of(size_t n_values, unsigned block, trpx::FrameGeom* g) {
     return true;
 }
 
+// One size check for every entry point (sizes may come straight from an untrusted .trpx header): frame count and
+// tiles must fit the 31-bit grids, and n_values * n_frames * 8 (the widest element) must not wrap.
+bool sizes_ok(const trpx::FrameGeom& g, size_t n_frames) {
+    if (n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles) return false;
+    const unsigned __int128 bytes = (unsigned __int128)g.n_values * n_frames * 8;
+    return bytes < ((unsigned __int128)1 << 62);
+}
+
 // workspace layouts ------------------------------------------------------------------------
 struct EncWs { size_t frame_size, tile_off, tile_bits, fused, total; };
 EncWs enc_ws(const trpx::FrameGeom& g, size_t n_frames) {
@@ -156,7 +164,7 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     if (!trpx_dtype_size(dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: unknown dtype %d", dtype);
     if (block == 0 || block > kMaxBlock)
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode: block=%u (supported: 1..%u; 12 is the tuned default, Terse.hpp:264)", block, kMaxBlock);
-    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles)
+    if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames))
         return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
     if (!pixels || !frame_offsets || !status || !workspace || (!out && out_capacity))
         return fail(TRPX_ERR_INVALID_ARG, "trpx_encode: null pointer");
@@ -229,7 +237,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: stream signed=%d into dtype %d: only same-signedness decode "
                     "is defined by the reference (Terse.hpp:356-357)", stream_signed, out_dtype);
-    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
+    if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || terse_bytes == 0)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: bad sizes");
     if (!terse || !pixels_out || !status || !workspace) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: null pointer");
     if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8 ||
@@ -277,7 +285,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
                             bool clear_status, void* stream) {
     trpx::FrameGeom g;
     if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: the decode index needs block=12");
-    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !n_frames || !terse_bytes)
+    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || !terse_bytes)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: bad dtype/sizes");
     if (!terse || !frame_offsets || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: null pointer");
     if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8)
@@ -312,7 +320,7 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: block=%u", block);
     if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: only same-signedness decode (Terse.hpp:356-357)");
-    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
+    if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || terse_bytes == 0)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: bad sizes");
     if (!terse || !pixels_out || !status || !index || !frame_offsets)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: null pointer");
@@ -341,7 +349,7 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
     const size_t es = out_dtype == TRPX_F32 ? 4 : out_dtype == TRPX_F64 ? 8 : trpx_dtype_size(out_dtype);
     if (!es) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: unknown dtype %d", out_dtype);
     if (block == 0 || block > kMaxBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_convert: block=%u", block);
-    if (!geom_of(n_values, block, &g) || n_frames == 0 || n_frames > 0x7FFFFFFFull / g.n_tiles || terse_bytes == 0)
+    if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || terse_bytes == 0)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: bad sizes");
     if (!terse || !pixels_out || !status || !workspace) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: null pointer");
     if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8 ||
@@ -406,6 +414,11 @@ int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_fr
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     const size_t es = trpx_dtype_size(dtype);
     if (!es || !pixels || !out || !total_bytes) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode_host: bad argument");
+    {
+        trpx::FrameGeom g0;
+        if (!geom_of(n_values, block, &g0)) return fail(block == 0 || block > kMaxBlock ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG, "trpx_encode_host: unsupported sizes/block (block=%u)", block);
+        if (!sizes_ok(g0, n_frames)) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode_host: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
+    }
     const size_t in_bytes = n_values * n_frames * es;
     const size_t cap = trpx::align_up(n_frames * trpx_worst_case_bytes(dtype, n_values, block), 16);
     const size_t ws_bytes = trpx_encode_workspace_bytes(dtype, n_values, n_frames, block);
@@ -452,6 +465,10 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     const size_t es = out_dtype == TRPX_F32 ? 4 : out_dtype == TRPX_F64 ? 8 : trpx_dtype_size(out_dtype);
     if (!es || !terse || !pixels_out || !terse_bytes) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_host: bad argument");
+    {
+        trpx::FrameGeom g0;
+        if (geom_of(n_values, block, &g0) && !sizes_ok(g0, n_frames)) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_host: bad sizes");
+    }
     const size_t out_bytes = n_values * n_frames * es;
     const size_t ws_bytes = trpx_decode_workspace_bytes(TRPX_U8, n_values, n_frames, block);
     if (!ws_bytes) return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
@@ -501,6 +518,8 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     if (!geom_of(n_values, block, &g))
         return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
                     "trpx_frame_offsets_host: unsupported sizes/block (block=%u)", block);
+    if (!sizes_ok(g, n_frames) || n_frames > terse_bytes)                     // every frame is at least one byte (Terse.hpp:547)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_frame_offsets_host: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
     const DecWs w = dec_ws(g, n_frames);
     DevBuf d_in, d_st, d_ws;
     HIP_TRY(d_in.alloc(trpx::align_up(terse_bytes, 4) + 8));
