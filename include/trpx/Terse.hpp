@@ -74,6 +74,13 @@ public:
     /// Reads a Terse object written by write() / the reference (Terse.hpp:279, :485-498).
     explicit Terse(std::ifstream& istream) { f_read(istream); }
 
+    /// Copy-constructible like the reference's class (the device-side copy of the stack is not shared); not assignable.
+    Terse(Terse const& o)
+        : d_signed(o.d_signed), d_block(o.d_block), d_size(o.d_size), d_prolix_bits(o.d_prolix_bits), d_dim(o.d_dim),
+          d_terse_data(o.d_terse_data), d_frame_sizes(o.d_frame_sizes) {}
+    Terse& operator=(Terse const&) = delete;
+    ~Terse() { f_drop_stack(); }
+
     /// Appends one frame (Terse.hpp:290-302).
     template <typename Iterator>
     void push_back(Iterator const data, std::size_t const size) { push_back(data, size, 1); }
@@ -122,13 +129,19 @@ public:
         if (frame >= number_of_frames()) throw std::invalid_argument("prolix: frame index out of range");
         if (d_signed && std::is_unsigned_v<V>)
             throw std::invalid_argument("signed data cannot be decompressed into unsigned data");
-        const std::size_t start = std::accumulate(d_frame_sizes.begin(), d_frame_sizes.begin() + frame, std::size_t(0));
         std::vector<V> tmp;
         V* dst;
         if constexpr (std::is_pointer_v<Iterator>) dst = begin;
         else { tmp.resize(d_size); dst = tmp.data(); }
-        detail::check(trpx_decode_host(d_signed, detail::out_dtype_of<V>(), d_terse_data.data() + start, d_frame_sizes[frame],
-                                       nullptr, d_size, 1, d_block, dst, -1), "Terse::prolix");
+        // src/prolix.cpp:69-92 calls this once per frame: the compressed stack is uploaded once and kept on the device
+        // (trpx_stack_*), a window of frames is expanded per device call, a call normally only copies its frame back
+        if (!d_stack) {
+            std::vector<std::uint64_t> offs(d_frame_sizes.size() + 1, 0);
+            for (std::size_t f = 0; f < d_frame_sizes.size(); ++f) offs[f + 1] = offs[f] + d_frame_sizes[f];
+            detail::check(trpx_stack_open(&d_stack, d_signed, d_terse_data.data(), d_terse_data.size(), offs.data(), d_size,
+                                          d_frame_sizes.size(), d_block, 0, -1), "Terse::prolix");
+        }
+        detail::check(trpx_stack_read(d_stack, frame, detail::out_dtype_of<V>(), dst), "Terse::prolix");
         if constexpr (!std::is_pointer_v<Iterator>) std::copy(tmp.begin(), tmp.end(), begin);
     }
 
@@ -191,10 +204,17 @@ private:
     std::vector<std::size_t> d_dim;
     std::vector<std::uint8_t> d_terse_data;
     std::vector<std::size_t> d_frame_sizes;
+    trpx_stack* d_stack = nullptr;                     // the stack on the device, for prolix(it, frame); dropped when frames are added
+
+    void f_drop_stack() {
+        if (d_stack) trpx_stack_close(d_stack);
+        d_stack = nullptr;
+    }
 
     template <typename Iterator>
     void f_compress(Iterator data, std::size_t n_frames) {                        // Terse.hpp:500-549 -> device
         using V = typename std::iterator_traits<Iterator>::value_type;
+        f_drop_stack();
         if constexpr (sizeof(V) == 8) {
             // 64-bit integers (what src/terse.cpp:120-123 makes of float / double images): the stream of values that fit
             // 32 bits is the same whatever the container's type, so they are narrowed here; wider values are refused --

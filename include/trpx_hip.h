@@ -238,6 +238,22 @@ int trpx_header_parse(const char* data, size_t len, trpx_header* h, size_t* payl
 size_t trpx_header_format_indexed(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, char* buf, size_t buf_cap);
 size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity);
 
+/* ---- host callers that work frame by frame ---------------------------------------------
+ * src/prolix.cpp:69-92 expands a .trpx file with one `trpx_data.prolix(image, i)` per frame, src/terse.cpp:63-69 pushes
+ * one image at a time.  The *_host entry points keep their device buffers per calling thread between calls (no
+ * allocation per frame; trpx_host_release frees them).  For the expanding loop a stack object keeps the compressed stack
+ * on the device: trpx_stack_open uploads it once (frame_offsets may be NULL: the frames are then located by the serial
+ * walk, Terse.hpp:562-585, max_bits as in trpx_frame_offsets_host), trpx_stack_read(frame) expands a window of frames
+ * starting at `frame` in ONE device call on a miss (<= 64 MB of pixels) and afterwards only copies the frame asked for
+ * -- any output type of trpx_decode_host.  Not thread safe per object (the reference's prolix is not const either,
+ * Terse.hpp:387-388). */
+typedef struct trpx_stack trpx_stack;
+int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                    size_t n_values, size_t n_frames, unsigned block, unsigned max_bits, int device);
+int trpx_stack_read(trpx_stack* stack, size_t frame, int out_dtype, void* pixels_out);
+void trpx_stack_close(trpx_stack* stack);
+void trpx_host_release(void);
+
 /* ---- multi-GPU (SURVEY.md section 8 row e): frames shard across GPUs, one process per GPU ----------------------
  * A frame's stream does not depend on its neighbours -- the header state resets per frame and every frame starts byte
  * aligned (Terse.hpp:502-505, :359) -- so rank r encodes its contiguous frame range with trpx_encode and keeps its

@@ -24,6 +24,9 @@ const char* trpx_last_error_string(void) { return "host sanitizer build: no devi
 int trpx_encode_host(int, const void*, size_t, size_t, unsigned, uint8_t*, size_t, size_t*, uint64_t*, uint32_t*, int) { return no_device(); }
 int trpx_decode_host(int, int, const uint8_t*, size_t, const uint64_t*, size_t, size_t, unsigned, void*, int) { return no_device(); }
 int trpx_frame_offsets_host(const uint8_t*, size_t, size_t, size_t, unsigned, unsigned, uint64_t*, int) { return no_device(); }
+int trpx_stack_open(trpx_stack**, int, const uint8_t*, size_t, const uint64_t*, size_t, size_t, unsigned, unsigned, int) { return no_device(); }
+int trpx_stack_read(trpx_stack*, size_t, int, void*) { return no_device(); }
+void trpx_stack_close(trpx_stack*) {}
 size_t trpx_worst_case_bytes(int, size_t n, unsigned) { return 8 * n + 64; }
 size_t trpx_dtype_size(int d) { return d < 2 ? 1 : d < 4 ? 2 : 4; }
 }

@@ -17,3 +17,24 @@ for rep in range(4):
     _lib.check(L.trpx_decode_host(0, _lib.U16, out.ctypes.data, total.value, offs.ctypes.data, n, frames, 12, back.ctypes.data, -1))
     t2 = time.perf_counter()
     print(f"rep {rep}: encode_host {1e3 * (t1 - t0):7.1f} ms ({px.nbytes / (t1 - t0) / 1e9:5.1f} GB/s of pixels)  decode_host {1e3 * (t2 - t1):7.1f} ms ({px.nbytes / (t2 - t1) / 1e9:5.1f} GB/s)  exact {bool((back == px).all())}")
+
+# per-frame expansion (src/prolix.cpp:69-92's loop): the stack stays on the device, a window of frames per device call
+h = C.c_void_p()
+_lib.check(L.trpx_stack_open(C.byref(h), 0, out.ctypes.data, total.value, offs.ctypes.data, n, frames, 12, 0, -1))
+one = np.empty(n, np.uint16)
+for rep in range(3):
+    t0 = time.perf_counter()
+    for f in range(frames):
+        L.trpx_stack_read(h, f, _lib.U16, back[f].ctypes.data)
+    t1 = time.perf_counter()
+    print(f"rep {rep}: trpx_stack_read, {frames} frames one by one: {1e6 * (t1 - t0) / frames:7.1f} us per frame ({px.nbytes / (t1 - t0) / 1e9:5.1f} GB/s)  exact {bool((back == px).all())}")
+L.trpx_stack_close(h)
+# pure transfer time of the same bytes (pageable host memory, like the callers'), for the ratio
+import torch
+d_px = torch.empty(px.nbytes, dtype=torch.uint8, device="cuda"); d_out = torch.empty(total.value, dtype=torch.uint8, device="cuda")
+hp = torch.from_numpy(px.view(np.uint8).reshape(-1)); ho = torch.from_numpy(out[: total.value])
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d_px.copy_(hp); ho.copy_(d_out); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    print(f"rep {rep}: bare copies (pixels H2D + stream D2H, pageable): {1e3 * (t1 - t0):7.1f} ms")

@@ -59,6 +59,10 @@ SYMBOLS = {
     "trpx_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
     "trpx_comm_destroy": (_I, [_P]),
     "trpx_shard_last_error": (C.c_char_p, []),
+    "trpx_stack_open": (_I, [C.POINTER(_P), _I, _P, _SZ, _P, _SZ, _SZ, _U, _U, _I]),
+    "trpx_stack_read": (_I, [_P, _SZ, _I, _P]),
+    "trpx_stack_close": (None, [_P]),
+    "trpx_host_release": (None, []),
     "trpx_set_encode_path": (_I, [_I]),
     "trpx_profile_enable": (_I, [_I]),
     "trpx_profile_read": (_I, [C.POINTER(C.c_float), _I]),

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/trpx_hip.h"
@@ -399,13 +400,45 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
 }
 
 // ---- host-pointer convenience wrappers ---------------------------------------------------
+// The callers of the reference's API work frame by frame from host memory (src/terse.cpp:63-69 pushes one image at a
+// time, src/prolix.cpp:69-92 expands one frame at a time): a device allocation per call would cost more than the
+// codec.  Every thread keeps ONE grow-only set of device buffers per role (freed by trpx_host_release or at exit of the
+// process); the host wrappers carve their pixels / stream / offsets / status / workspace from it.
+}  // extern "C"
 namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+struct Arena {
+    enum { kPixels, kStream, kOffsets, kStatus, kWorkspace, kSlots };
+    void* p[kSlots] = {};
+    size_t cap[kSlots] = {};
+    int device = -1;
+    hipError_t get(int slot, size_t n, void** out) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev != device) { release(); device = dev; }
+        if (cap[slot] < n) {
+            if (p[slot]) (void)hipFree(p[slot]);
+            p[slot] = nullptr; cap[slot] = 0;
+            const size_t want = n + n / 8 + 256;             // a little head room: stacks of slightly different sizes reuse it
+            e = hipMalloc(&p[slot], want);
+            if (e != hipSuccess) return e;
+            cap[slot] = want;
+        }
+        *out = p[slot];
+        return hipSuccess;
+    }
+    void release() {
+        for (int i = 0; i < kSlots; ++i) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+    }
 };
+Arena& arena() {
+    static thread_local Arena* a = new Arena;                // (not destroyed at thread exit: the HIP runtime may already be gone)
+    return *a;
+}
 }  // namespace
+extern "C" {
+
+void trpx_host_release(void) { arena().release(); }
 
 int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
                      size_t out_capacity, size_t* total_bytes, uint64_t* frame_offsets, uint32_t* prolix_bits,
@@ -424,12 +457,13 @@ int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_fr
     const size_t ws_bytes = trpx_encode_workspace_bytes(dtype, n_values, n_frames, block);
     if (!ws_bytes) return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
                                "trpx_encode_host: unsupported sizes/block (block=%u)", block);
-    DevBuf d_px, d_out, d_off, d_st, d_ws;
-    HIP_TRY(d_px.alloc(in_bytes));
-    HIP_TRY(d_out.alloc(cap));
-    HIP_TRY(d_off.alloc(8 * (n_frames + 1)));
-    HIP_TRY(d_st.alloc(4 * TRPX_STATUS_WORDS));
-    HIP_TRY(d_ws.alloc(ws_bytes));
+    struct { void* p; } d_px, d_out, d_off, d_st, d_ws;
+    Arena& A = arena();
+    HIP_TRY(A.get(Arena::kPixels, in_bytes, &d_px.p));
+    HIP_TRY(A.get(Arena::kStream, cap, &d_out.p));
+    HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1), &d_off.p));
+    HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
+    HIP_TRY(A.get(Arena::kWorkspace, ws_bytes, &d_ws.p));
     HIP_TRY(hipMemcpy(d_px.p, pixels, in_bytes, hipMemcpyHostToDevice));
     int rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
                          static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
@@ -473,15 +507,16 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
     const size_t ws_bytes = trpx_decode_workspace_bytes(TRPX_U8, n_values, n_frames, block);
     if (!ws_bytes) return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
                                "trpx_decode_host: unsupported sizes/block (block=%u)", block);
-    DevBuf d_in, d_out, d_off, d_st, d_ws;
-    HIP_TRY(d_in.alloc(trpx::align_up(terse_bytes, 4) + 8));
-    HIP_TRY(d_out.alloc(out_bytes));
-    HIP_TRY(d_st.alloc(4 * TRPX_STATUS_WORDS));
-    HIP_TRY(d_ws.alloc(ws_bytes));
-    HIP_TRY(hipMemset(d_in.p, 0, trpx::align_up(terse_bytes, 4) + 8));
+    struct { void* p = nullptr; } d_in, d_out, d_off, d_st, d_ws;
+    Arena& A = arena();
+    HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
+    HIP_TRY(A.get(Arena::kPixels, out_bytes, &d_out.p));
+    HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
+    HIP_TRY(A.get(Arena::kWorkspace, ws_bytes, &d_ws.p));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));   // the bytes behind the stream read as zero
     HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
     if (frame_offsets) {
-        HIP_TRY(d_off.alloc(8 * (n_frames + 1)));
+        HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1), &d_off.p));
         HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
     }
     // Same signedness: the tuned decoders.  They report CORRUPT for a block wider than the output type, which is also
@@ -521,11 +556,12 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     if (!sizes_ok(g, n_frames) || n_frames > terse_bytes)                     // every frame is at least one byte (Terse.hpp:547)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_frame_offsets_host: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
     const DecWs w = dec_ws(g, n_frames);
-    DevBuf d_in, d_st, d_ws;
-    HIP_TRY(d_in.alloc(trpx::align_up(terse_bytes, 4) + 8));
-    HIP_TRY(d_st.alloc(4 * TRPX_STATUS_WORDS));
-    HIP_TRY(d_ws.alloc(w.total));
-    HIP_TRY(hipMemset(d_in.p, 0, trpx::align_up(terse_bytes, 4) + 8));
+    struct { void* p = nullptr; } d_in, d_st, d_ws;
+    Arena& A = arena();
+    HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
+    HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
+    HIP_TRY(A.get(Arena::kWorkspace, w.total, &d_ws.p));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));
     HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
     trpx::DecodeArgs a{};
     a.terse = static_cast<const uint8_t*>(d_in.p);
@@ -547,6 +583,116 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     if (st[0]) return fail((int)st[0], "trpx_frame_offsets_host: corrupt or truncated stack");
     HIP_TRY(hipMemcpy(frame_offsets, a.walk_offsets, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
     return TRPX_OK;
+}
+
+
+// ---- a compressed stack kept on the device, read frame by frame (src/prolix.cpp:69-92's loop shape) --------------------
+struct trpx_stack {
+    int device = 0;
+    int stream_signed = 0;
+    size_t n_values = 0, n_frames = 0, terse_bytes = 0;
+    unsigned block = 12;
+    void* d_terse = nullptr;       // the stack (+ zero tail)
+    void* d_offs = nullptr;        // u64[n_frames + 1]
+    void* d_status = nullptr;
+    void* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    void* d_window = nullptr;      // decoded frames [win_first, win_first + win_count) as win_dtype
+    size_t window_cap = 0, win_first = 0, win_count = 0, window_frames = 0;
+    int win_dtype = -1;
+    std::vector<uint64_t> offs;    // host copy of the frame offsets
+};
+
+static void stack_free(trpx_stack* s) {
+    if (!s) return;
+    for (void* q : {s->d_terse, s->d_offs, s->d_status, s->d_ws, s->d_window}) if (q) (void)hipFree(q);
+    delete s;
+}
+
+int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                    size_t n_values, size_t n_frames, unsigned block, unsigned max_bits, int device) {
+    if (!handle) return fail(TRPX_ERR_INVALID_ARG, "trpx_stack_open: null handle");
+    *handle = nullptr;
+    if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_stack_open: no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    trpx::FrameGeom g;
+    if (!terse || !terse_bytes || !geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || n_frames > terse_bytes)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_stack_open: bad argument / sizes");
+    std::vector<uint64_t> offs(n_frames + 1);
+    if (frame_offsets) memcpy(offs.data(), frame_offsets, 8 * (n_frames + 1));
+    else {
+        const int rc = trpx_frame_offsets_host(terse, terse_bytes, n_values, n_frames, block, max_bits ? max_bits : 32, offs.data(), -1);
+        if (rc) return rc;
+    }
+    if (offs[0] != 0 || offs[n_frames] > terse_bytes) return fail(TRPX_ERR_CORRUPT, "trpx_stack_open: frame offsets do not fit the stack");
+    for (size_t f = 0; f < n_frames; ++f)
+        if (offs[f + 1] <= offs[f]) return fail(TRPX_ERR_CORRUPT, "trpx_stack_open: frame offsets are not increasing");
+    trpx_stack* s = new trpx_stack;
+    HIP_TRY(hipGetDevice(&s->device));
+    s->stream_signed = stream_signed != 0;
+    s->n_values = n_values; s->n_frames = n_frames; s->terse_bytes = terse_bytes; s->block = block;
+    s->offs.swap(offs);
+    const size_t frame_bytes = n_values * 8;                                   // widest output (double)
+    s->window_frames = std::max<size_t>(1, std::min<size_t>(n_frames, (size_t(64) << 20) / frame_bytes));   // <= 64 MB of decoded frames
+    s->ws_bytes = trpx_decode_workspace_bytes(TRPX_U8, n_values, s->window_frames, block);
+    auto bail = [&](hipError_t e, const char* what) { stack_free(s); return fail(TRPX_ERR_HIP, "trpx_stack_open: %s: %s", what, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc(&s->d_terse, trpx::align_up(terse_bytes, 4) + 8)) != hipSuccess) return bail(e, "hipMalloc(stack)");
+    if ((e = hipMalloc(&s->d_offs, 8 * (n_frames + 1))) != hipSuccess) return bail(e, "hipMalloc(offsets)");
+    if ((e = hipMalloc(&s->d_status, 4 * TRPX_STATUS_WORDS)) != hipSuccess) return bail(e, "hipMalloc(status)");
+    if ((e = hipMalloc(&s->d_ws, s->ws_bytes ? s->ws_bytes : 256)) != hipSuccess) return bail(e, "hipMalloc(workspace)");
+    if ((e = hipMemset(s->d_terse, 0, trpx::align_up(terse_bytes, 4) + 8)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemcpy(s->d_terse, terse, terse_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(stack)");
+    if ((e = hipMemcpy(s->d_offs, s->offs.data(), 8 * (n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(offsets)");
+    *handle = s;
+    return TRPX_OK;
+}
+
+int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out) {
+    if (!s || !pixels_out || frame >= s->n_frames) return fail(TRPX_ERR_INVALID_ARG, "trpx_stack_read: bad argument");
+    const size_t es = out_dtype == TRPX_F32 ? 4 : out_dtype == TRPX_F64 ? 8 : trpx_dtype_size(out_dtype);
+    if (!es) return fail(TRPX_ERR_INVALID_ARG, "trpx_stack_read: unknown dtype %d", out_dtype);
+    HIP_TRY(hipSetDevice(s->device));
+    if (out_dtype != s->win_dtype || frame < s->win_first || frame >= s->win_first + s->win_count) {
+        // a miss: expand the window of frames that starts here (the callers of the reference walk the stack in order)
+        const size_t count = std::min(s->window_frames, s->n_frames - frame);
+        const size_t need = count * s->n_values * es;
+        if (s->window_cap < need) {
+            if (s->d_window) (void)hipFree(s->d_window);
+            s->d_window = nullptr; s->window_cap = 0;
+            HIP_TRY(hipMalloc(&s->d_window, need));
+            s->window_cap = need;
+        }
+        s->win_count = 0;
+        const uint64_t first_byte = s->offs[frame] & ~uint64_t(3);            // trpx_decode wants a 4-byte aligned stream
+        const uint8_t* base = static_cast<const uint8_t*>(s->d_terse) + first_byte;
+        std::vector<uint64_t> rel(count + 1);
+        for (size_t i = 0; i <= count; ++i) rel[i] = s->offs[frame + i] - first_byte;
+        HIP_TRY(hipMemcpy(static_cast<uint64_t*>(s->d_offs), rel.data(), 8 * (count + 1), hipMemcpyHostToDevice));
+        const size_t bytes = (size_t)rel[count];
+        bool convert = !(out_dtype <= TRPX_I32 && (s->stream_signed != 0) == (trpx_dtype_is_signed(out_dtype) != 0));
+        uint32_t st[TRPX_STATUS_WORDS];
+        for (;;) {                                                             // (same routing as trpx_decode_host)
+            const int rc = convert ? trpx_decode_convert(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs),
+                                                         s->n_values, count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status),
+                                                         s->d_ws, s->ws_bytes, nullptr)
+                                   : trpx_decode(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs), s->n_values,
+                                                 count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), s->d_ws, s->ws_bytes, nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
+            if (st[0] == TRPX_ERR_CORRUPT && !convert && es < 4) { convert = true; continue; }
+            break;
+        }
+        if (st[0]) return fail((int)st[0], "trpx_stack_read: corrupt or truncated stream (device status %u)", st[0]);
+        s->win_first = frame; s->win_count = count; s->win_dtype = out_dtype;
+    }
+    const size_t fb = s->n_values * es;
+    HIP_TRY(hipMemcpy(pixels_out, static_cast<const char*>(s->d_window) + (frame - s->win_first) * fb, fb, hipMemcpyDeviceToHost));
+    return TRPX_OK;
+}
+
+void trpx_stack_close(trpx_stack* s) {
+    if (s) { (void)hipSetDevice(s->device); stack_free(s); }
 }
 
 }  // extern "C"

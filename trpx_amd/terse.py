@@ -48,6 +48,7 @@ class Terse:
         self._prolix_bits = 0
         self._dim: list[int] = []
         self._data = bytearray()
+        self._stack, self._stack_len = None, -1      # device-resident copy of the stack (prolix), see _drop_stack
         self._frame_sizes: list[int] = []
         if data is not None:
             self.push_back(data)
@@ -110,11 +111,29 @@ class Terse:
             raise ValueError("signed data cannot be decompressed into unsigned data")            # Terse.hpp:356-357
         if not out.flags.c_contiguous:
             raise ValueError("output must be contiguous")
-        start = sum(self._frame_sizes[:frame])
-        chunk = np.frombuffer(self._data, np.uint8, self._frame_sizes[frame], start).copy()
-        check(lib().trpx_decode_host(int(self._signed), _code(out.dtype, True), chunk.ctypes.data, chunk.size, None,
-                                     self._size, 1, self._block, out.ctypes.data, self._device))
+        # src/prolix.cpp:69-92 calls this once per frame: the stack is uploaded once and kept on the device (trpx_stack_*),
+        # a window of frames is expanded per device call and a call normally only copies its frame back
+        if self._stack is None or self._stack_len != len(self._data):
+            self._drop_stack()
+            buf = np.frombuffer(self._data, np.uint8)
+            offs = np.concatenate([[0], np.cumsum(self._frame_sizes)]).astype(np.uint64)
+            h = C.c_void_p()
+            check(lib().trpx_stack_open(C.byref(h), int(self._signed), buf.ctypes.data, buf.size, offs.ctypes.data, self._size,
+                                        len(self._frame_sizes), self._block, 0, self._device))
+            self._stack, self._stack_len = h, len(self._data)
+        check(lib().trpx_stack_read(self._stack, frame, _code(out.dtype, True), out.ctypes.data))
         return out
+
+    def _drop_stack(self) -> None:
+        if getattr(self, "_stack", None) is not None:
+            lib().trpx_stack_close(self._stack)
+        self._stack, self._stack_len = None, -1
+
+    def __del__(self):
+        try:
+            self._drop_stack()
+        except Exception:
+            pass
 
     def prolix_stack(self, dtype) -> np.ndarray:
         """Decode every frame in ONE GPU call; returns [n_frames, size]."""
