@@ -51,6 +51,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
     __shared__ uint32_t s_chunk[kFrameChunkDw + 4];    // walker's window of the stream
     __shared__ uint8_t s_w[2][kStepBlocks + 4];        // [0] = width of the block before the super-step, [1 + i] = widths of its blocks (double buffered)
     __shared__ uint32_t s_goff[2][kStepGroups];        // frame-relative bit offset of each group's first block
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][kWave * kBlock * sizeof(T) / 4];   // a group's pixels, per extraction wave
     __shared__ uint32_t s_err;
 
     const uint32_t lane = (uint32_t)lane_id();
@@ -265,6 +266,27 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 }
                 T* __restrict__ dst = fout + (uint64_t)blk * kBlock;
                 uint64_t todo = __ballot(nb == kBlock);
+                if (todo == ~0ull) {
+                    // 64 full blocks: every lane leaves its 12 pixels in the wave's LDS row, then the wave stores the group
+                    // 16 bytes per lane -- whole lines per store instruction instead of 24-byte runs
+                    uint32_t* const stage = s_out[wave - 1];
+                    uint32_t* const row = stage + lane * (kBlock * (uint32_t)sizeof(T) / 4u);
+                    while (todo) {
+                        const int l0 = __builtin_ctzll(todo);
+                        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                        const bool mine = w == w0;
+                        uint32_t ss = sq;
+                        asm volatile("" : "+v"(ss));                                  // keep the specialised bodies out of LICM's reach
+                        if (mine) UnpackStageDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, row);
+                        todo &= ~__ballot(mine);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    store_group<T>(stage, fout + (uint64_t)((s - 1) * kStepBlocks + gi * kWave) * kBlock);
+                    __builtin_amdgcn_wave_barrier();                                  // (the row is rewritten by the next group)
+                    continue;
+                }
                 while (todo) {
                     const int l0 = __builtin_ctzll(todo);
                     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);

@@ -114,6 +114,78 @@ __device__ __forceinline__ void unpack_store_w(const uint32_t (&raw)[4 * RawQuad
     }
 }
 
+// The same extraction, but the block's 12 pixels go to the wavefront's LDS staging row instead of straight to memory
+// (`row` = staging + lane * 3 * sizeof(T) dwords, 8-byte aligned for 16/32-bit pixels): the wavefront then writes its
+// 64 blocks as whole 16-byte-per-lane stores (store_group), every store instruction covering consecutive bytes.
+// A lane-owned 24-byte run written as 16 + 8 byte non-temporal stores reaches 2.4 TB/s on MI355X, the same bytes
+// exchanged through LDS and stored 16 bytes per lane 5.4 TB/s (tools/wrbench.hip).
+template <typename T, int W>
+__device__ __forceinline__ void unpack_stage_w(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t* __restrict__ row) {
+    constexpr int bits = PixelTraits<T>::bits;
+    constexpr int NBITS = kBlock * W;
+    constexpr int ND = (NBITS + 31) / 32;
+    static_assert(ND + 1 <= 4 * RawQuads<T>::n, "field string must fit the loaded quads");
+    uint32_t x[ND ? ND : 1];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) x[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], s);   // string aligned to bit 0
+    uint32_t f[kBlock];
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k) {
+        if constexpr (W == 0) f[k] = 0u;
+        else {
+            const int bit = k * W;
+            uint32_t y = x[bit >> 5] >> (bit & 31);
+            if ((bit & 31) + W > 32) y |= x[(bit >> 5) + 1] << (32 - (bit & 31));
+            if (PixelTraits<T>::is_signed) f[k] = (uint32_t)((int32_t)(y << (32 - W)) >> (32 - W));   // sign-extend (:784-789)
+            else f[k] = W >= 32 ? y : y & ((1u << (W & 31)) - 1u);
+        }
+    }
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    if constexpr (bits == 32) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) reinterpret_cast<u2*>(row)[i] = u2{f[2 * i], f[2 * i + 1]};
+    } else if constexpr (bits == 16) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            reinterpret_cast<u2*>(row)[i] = u2{__builtin_amdgcn_perm(f[4 * i + 1], f[4 * i], 0x05040100u),
+                                               __builtin_amdgcn_perm(f[4 * i + 3], f[4 * i + 2], 0x05040100u)};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t lo = __builtin_amdgcn_perm(f[4 * i + 1], f[4 * i], 0x0c0c0400u);       // {0, 0, b.byte0, a.byte0}
+            const uint32_t hi = __builtin_amdgcn_perm(f[4 * i + 3], f[4 * i + 2], 0x0c0c0400u);
+            row[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+    }
+}
+
+// The wavefront's staged group (64 blocks = 768 pixels, consecutive in `staging`) -> memory, 16 bytes per lane and store.
+template <typename T>
+__device__ __forceinline__ void store_group(const uint32_t* __restrict__ staging, T* __restrict__ group_dst) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int kQuads = kWave * kBlock * (int)sizeof(T) / 16;            // 16-byte pieces of the group: 48 / 96 / 192
+    const int lane = lane_id();
+    const u4* src = reinterpret_cast<const u4*>(staging);
+    u4* dst = reinterpret_cast<u4*>(group_dst);
+#pragma unroll
+    for (int i = 0; i < (kQuads + kWave - 1) / kWave; ++i) {
+        const int q = i * kWave + lane;
+        if (kQuads % kWave == 0 || q < kQuads) __builtin_nontemporal_store(src[q], dst + q);
+    }
+}
+
+template <typename T, int LO, int HI>
+struct UnpackStageDispatch {
+    static __device__ __forceinline__ void run(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t w0, uint32_t* row) {
+        if constexpr (LO == HI) unpack_stage_w<T, LO>(raw, s, row);
+        else {
+            constexpr int MID = (LO + HI) / 2;
+            if (w0 <= (uint32_t)MID) UnpackStageDispatch<T, LO, MID>::run(raw, s, w0, row);
+            else UnpackStageDispatch<T, MID + 1, HI>::run(raw, s, w0, row);
+        }
+    }
+};
+
 template <typename T, int LO, int HI>
 struct UnpackStoreDispatch {
     static __device__ __forceinline__ void run(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t w0, T* dst) {
