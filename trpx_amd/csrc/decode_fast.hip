@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
 // k_unpack_tiles
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 6) void k_unpack_tiles(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                               uint32_t tiles_per_frame,
                                                               const uint8_t* __restrict__ widths,
@@ -204,10 +204,11 @@ __global__ __launch_bounds__(kThreads, 6) void k_unpack_tiles(const uint8_t* __r
                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
     __shared__ uint32_t s_image[unpack_image_dwords<T>()];
     __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[unpack_stage_dwords<T>()];
     if (status[0] != 0) return;                             // corrupt chain: produce nothing
     const uint64_t tile = blockIdx.x;
     unpack_tile<T>(terse, terse_bytes, frame_offsets, g, (uint32_t)(tile / tiles_per_frame), (uint32_t)(tile % tiles_per_frame),
-                   widths, tile_off, pixels_out, status, s_image, s_wtot);
+                   widths, tile_off, pixels_out, status, s_image, s_wtot, s_stage);
 }
 
 template <typename T>

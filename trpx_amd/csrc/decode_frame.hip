@@ -49,9 +49,13 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                                                                uint32_t* __restrict__ status) {
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
     __shared__ uint32_t s_chunk[kFrameChunkDw + 4];    // walker's window of the stream
-    __shared__ uint8_t s_w[2][kStepBlocks + 4];        // [0] = width of the block before the super-step, [1 + i] = widths of its blocks (double buffered)
-    __shared__ uint32_t s_goff[2][kStepGroups];        // frame-relative bit offset of each group's first block
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][kWave * kBlock * sizeof(T) / 4];   // a group's pixels, per extraction wave
+    __shared__ uint8_t s_w[2][kStepBlocks + 68];       // [0] = width of the block before the super-step, [1 + i] = widths of its blocks (double buffered); 64 spare bytes behind (fast steps)
+    __shared__ uint32_t s_goff[3][kStepGroups < kWave ? kWave : kStepGroups];   // [0..1]: frame-relative bit offset of each group's first block; [2]: spare row (fast steps)
+    uint8_t* const s_wb = &s_w[0][0];
+    uint32_t* const s_goffx = &s_goff[0][0];
+    constexpr uint32_t kGoffRow = kStepGroups < kWave ? kWave : kStepGroups;
+    constexpr bool kStaged = sizeof(T) == 4;           // (8/16-bit pixels: direct stores are as fast -- int8 stacks 0.24 direct / 0.26 ms staged)
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][kStaged ? kWave * kBlock * sizeof(T) / 4 : 4];   // a group's pixels, per extraction wave
     __shared__ uint32_t s_err;
 
     const uint32_t lane = (uint32_t)lane_id();
@@ -104,26 +108,32 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         uint32_t stride = 1u + kBlock * w_prev;
                         int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
                         uint32_t wide = 0;                                // widest explicit block of these steps (checked once, after them)
+                        const uint32_t wbase = (uint32_t)(buf * (kStepBlocks + 68)) + 1u - s * kStepBlocks;   // s_w index of block 0
                         while (b + 64u <= fast_end && (int32_t)pos < pos_max) {
-                            const uint32_t fbit = frame_sh + pos + __umul24(lane, stride) - 32u * (uint32_t)c_lo;
+                            // One step = one run of equal widths + the explicit header behind it.  Everything that does not
+                            // need `first` is issued before the ballot (every lane decodes "its" explicit header,
+                            // Terse.hpp:362-370), the step has one branch (the loop's), and the width / group-offset stores
+                            // are unconditional: lanes behind the step's last block write values the next step overwrites,
+                            // lanes that start no 64-block group write to a spare row.  (Walker alone: 0.23 -> 0.20 ms per
+                            // 2000-frame stack against the branchy version.)
+                            const uint32_t lpos = pos + __umul24(lane, stride);
+                            const uint32_t fbit = frame_sh - 32u * (uint32_t)c_lo + lpos;
                             const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
+                            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
+                            const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
+                            const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;   // header + payload bits
                             const uint64_t stop = ~__ballot((bits & 1u) != 0u);                           // Terse.hpp:361
                             const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
                             const bool run = first >= 64u;                                              // all 64 repeat w_prev
-                            uint32_t e_w = w_prev, adv = 0;
-                            if (!run) {                                                                 // (wave-uniform branch)
-                                const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
-                                const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
-                                const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;   // header + payload bits
-                                e_w = (uint32_t)__builtin_amdgcn_readlane((int)wk, (int)first);
-                                adv = (uint32_t)__builtin_amdgcn_readlane((int)advk, (int)first);
-                            }
+                            const uint32_t src = run ? 63u : first;
+                            const uint32_t x_w = (uint32_t)__builtin_amdgcn_readlane((int)wk, (int)src);
+                            const uint32_t x_adv = (uint32_t)__builtin_amdgcn_readlane((int)advk, (int)src);
+                            const uint32_t e_w = run ? w_prev : x_w, adv = run ? 0u : x_adv;
                             wide = e_w > wide ? e_w : wide;
-                            const uint32_t n_done = run ? 64u : first + 1u, rel = b - s * kStepBlocks;
-                            if (lane < n_done) {
-                                s_w[buf][1 + rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
-                                if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + __umul24(lane, stride);
-                            }
+                            const uint32_t n_done = run ? 64u : first + 1u;
+                            s_wb[wbase + b + lane] = (uint8_t)(lane < first ? w_prev : e_w);
+                            const uint32_t rl = b - s * kStepBlocks + lane;
+                            s_goffx[(rl & (kWave - 1)) == 0 && lane < n_done ? buf * kGoffRow + (rl >> 6) : 2 * kGoffRow + lane] = lpos;
                             pos += first * stride + adv;                                                // (bounded by pos_max: inside the window)
                             b += n_done;
                             w_prev = e_w;
@@ -241,10 +251,16 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
 
                 const uint32_t len = nb ? hl + __umul24((uint32_t)nb, w) : 0u;
                 const uint32_t inc = wave_inclusive_scan(len);
+#ifdef TRPX_DEC_NO_EXTRACT
+                if (inc == 0xFFFFFFFFu) fout[0] = (T)w;                               // (diagnostic build: no loads, no extraction, no stores)
+                continue;
+#endif
                 const uint32_t q = frame_sh + s_goff[pbuf][gi] + (inc - len) + hl;    // first payload bit, relative to dword frame_dw
                 const uint32_t dq = q >> 5, sq = q & 31u;
-                // (Issuing the NEXT group's loads before extracting this one was measured: a second set of raw registers
-                // means 64 VGPRs with spills at 8 workgroups per CU, 0.39 ms instead of 0.32 ms.)
+                // (Issuing the NEXT group's loads before extracting this one was measured twice: a second set of raw registers
+                // means 64 VGPRs with spills at 8 workgroups per CU, 0.39 ms instead of 0.32 ms; only the first 16 bytes
+                // per lane in flight -- enough for widths <= 8 -- still 0.355 ms: the next group's width reads and scan
+                // in front of the extraction cost more than the exposed L2 round trip.)
                 // All NQ quads, whatever the widths: a 16-byte load more per lane is cheaper than a wavefront max of the
                 // widths, and the extra bytes are the neighbours' (same cache lines).
                 const uint32_t last_dw = (uint32_t)__builtin_amdgcn_readlane((int)dq, 63) + 4u * NQ;   // lanes ascend in position
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 }
                 T* __restrict__ dst = fout + (uint64_t)blk * kBlock;
                 uint64_t todo = __ballot(nb == kBlock);
-                if (todo == ~0ull) {
+                if (kStaged && todo == ~0ull) {
                     // 64 full blocks: every lane leaves its 12 pixels in the wave's LDS row, then the wave stores the group
                     // 16 bytes per lane -- whole lines per store instruction instead of 24-byte runs
                     uint32_t* const stage = s_out[wave - 1];

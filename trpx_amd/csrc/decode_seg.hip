@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
 // Tiles of the listed frames (the frames k_decode_frames gave up on -- its serial walker met an explicit header every
 // few blocks -- after k_seg_frames has walked them): a fixed grid strides over (listed frame, tile) pairs.
 template <typename T>
-__global__ __launch_bounds__(kThreads, 6) void k_unpack_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 6) void k_unpack_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                const uint8_t* __restrict__ widths,
                                                                const uint64_t* __restrict__ tile_off,
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_unpack_listed(const uint8_t* __
                                                                uint32_t* __restrict__ status) {
     __shared__ uint32_t s_image[unpack_image_dwords<T>()];
     __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[unpack_stage_dwords<T>()];
     const uint32_t count = list[0];
     if (count == 0u || status[0] != 0u) return;
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_unpack_listed(const uint8_t* __
     for (uint64_t i = blockIdx.x; i < total; i += gridDim.x) {
         const uint32_t frame = list[1 + (uint32_t)(i / tpf)];
         if (!unpack_tile<T>(terse, terse_bytes, frame_offsets, g, frame, (uint32_t)(i % tpf), widths, tile_off, pixels_out, status,
-                            s_image, s_wtot))
+                            s_image, s_wtot, s_stage))
             return;
         __syncthreads();
     }

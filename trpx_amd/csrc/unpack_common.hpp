@@ -34,6 +34,29 @@ __device__ __forceinline__ void store_block(T* __restrict__ dst, const uint32_t 
     }
 }
 
+// 12 decoded values -> the lane's LDS staging row (see unpack_stage_w / store_group).
+template <typename T>
+__device__ __forceinline__ void stage_block(uint32_t* __restrict__ row, const uint32_t (&u)[kBlock]) {
+    constexpr int bits = PixelTraits<T>::bits;
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    if constexpr (bits == 32) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) reinterpret_cast<u2*>(row)[i] = u2{u[2 * i], u[2 * i + 1]};
+    } else if constexpr (bits == 16) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            reinterpret_cast<u2*>(row)[i] = u2{__builtin_amdgcn_perm(u[4 * i + 1], u[4 * i], 0x05040100u),
+                                               __builtin_amdgcn_perm(u[4 * i + 3], u[4 * i + 2], 0x05040100u)};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t lo = __builtin_amdgcn_perm(u[4 * i + 1], u[4 * i], 0x0c0c0400u);
+            const uint32_t hi = __builtin_amdgcn_perm(u[4 * i + 3], u[4 * i + 2], 0x0c0c0400u);
+            row[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+    }
+}
+
 // Extract the 12 W-bit fields that start at bit `q` of the LDS image; static shifts.
 template <typename T, int W>
 __device__ __forceinline__ void unpack_payload_w(const uint32_t* __restrict__ image, uint32_t q, uint32_t (&u)[kBlock]) {

@@ -8,19 +8,25 @@
 namespace trpx {
 
 template <typename T> constexpr int unpack_sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
+// Staged (LDS-transposed) stores pay for 32-bit pixels (48-byte runs per lane: the eight 4096 x 4096 int32 frames unpack in
+// 0.12 instead of 0.29 ms); for 8/16-bit pixels the direct 8..24-byte stores are as fast and the LDS row would cost a
+// workgroup per CU (measured: 2000 x 512 x 512 u16 with index 0.311 direct / 0.321 ms staged).
+template <typename T> constexpr bool unpack_staged() { return sizeof(T) == 4; }
+template <typename T> constexpr int unpack_stage_dwords() { return unpack_staged<T>() ? 4 * kWave * kBlock * (int)sizeof(T) / 4 : 4; }
 template <typename T>
 constexpr int unpack_image_dwords() { return unpack_sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 12; }
 
 // One tile (kSub * 256 blocks) of one frame: widths -> lengths -> scan -> stream bytes to LDS -> extraction -> stores.
-// Called by all 256 threads of a workgroup; s_image / s_wtot are the workgroup's LDS (unpack_image_dwords<T>() and
-// 4 * unpack_sub_tiles<T>() dwords).  Returns false when the index does not fit the frame (status set).
+// Called by all 256 threads of a workgroup; s_image / s_wtot / s_stage are the workgroup's LDS (unpack_image_dwords<T>(),
+// 4 * unpack_sub_tiles<T>() and unpack_stage_dwords<T>() dwords; s_stage: one row of 64 blocks per wavefront, through which
+// a wavefront's pixels leave as whole 16-byte-per-lane stores).  Returns false when the index does not fit the frame (status set).
 template <typename T>
 __device__ __forceinline__ bool unpack_tile(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                             const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t frame,
                                             uint32_t t, const uint8_t* __restrict__ widths,
                                             const uint64_t* __restrict__ tile_off, T* __restrict__ pixels_out,
                                             uint32_t* __restrict__ status, uint32_t* __restrict__ s_image,
-                                            uint32_t* __restrict__ s_wtot) {
+                                            uint32_t* __restrict__ s_wtot, uint32_t* __restrict__ s_stage) {
     constexpr int kSub = unpack_sub_tiles<T>();
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id(), wave = wave_id();
@@ -102,7 +108,16 @@ __device__ __forceinline__ bool unpack_tile(const uint8_t* __restrict__ terse, u
             if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(s_image, qq, w0 > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w0, u);
             todo &= ~__ballot(mine);
         }
-        if (nb[r] == kBlock) {
+        if (unpack_staged<T>() && __ballot(nb[r] == kBlock) == ~0ull) {   // the wavefront's 64 blocks are all full: staged, coalesced stores
+            if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
+            uint32_t* const st = s_stage + wave * (kWave * kBlock * (int)sizeof(T) / 4);
+            stage_block<T>(st + lane * (kBlock * (int)sizeof(T) / 4), u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            store_group<T>(st, fout + (uint64_t)(b - (uint32_t)lane) * kBlock);
+            __builtin_amdgcn_wave_barrier();                // (the row is rewritten in the next round)
+        } else if (nb[r] == kBlock) {
             if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
             store_block<T>(fout + (uint64_t)b * kBlock, u);
         } else if (nb[r]) {                                 // the frame's last, partial block: generic
