@@ -23,7 +23,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 U8, I8, U16, I16, U32, I32, U64, I64 = range(8)
 _NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.int8): I8, np.dtype(np.uint16): U16,
           np.dtype(np.int16): I16, np.dtype(np.uint32): U32, np.dtype(np.int32): I32,
-          np.dtype(np.uint64): U64, np.dtype(np.int64): I64}
+          np.dtype(np.uint64): U64, np.dtype(np.int64): I64,
+          np.dtype(np.float32): 8, np.dtype(np.float64): 9}     # decode() output only (Terse.hpp:379-383)
 _SFX = {U8: "u8", I8: "i8", U16: "u16", I16: "i16", U32: "u32", I32: "i32", U64: "u64", I64: "i64"}
 SEED = 20240807
 

@@ -31,14 +31,16 @@
 #include <time.h>
 
 enum { TRPX_U8 = 0, TRPX_I8 = 1, TRPX_U16 = 2, TRPX_I16 = 3, TRPX_U32 = 4, TRPX_I32 = 5,
-       TRPX_U64 = 6, TRPX_I64 = 7 };
+       TRPX_U64 = 6, TRPX_I64 = 7,
+       ORACLE_F32 = 8, ORACLE_F64 = 9 };   /* decode output only: Terse.hpp:379-383 (non-integral iterators) */
 
 static unsigned dtype_bytes(int dt) {
     switch (dt) {
     case TRPX_U8: case TRPX_I8: return 1;
     case TRPX_U16: case TRPX_I16: return 2;
     case TRPX_U32: case TRPX_I32: return 4;
-    case TRPX_U64: case TRPX_I64: return 8;
+    case TRPX_U64: case TRPX_I64: case ORACLE_F64: return 8;
+    case ORACLE_F32: return 4;
     }
     return 0;
 }
@@ -178,6 +180,9 @@ static inline void store_elem_clamped(int dt, void* p, size_t i, int64_t v, int 
     case TRPX_U32: ((uint32_t*)p)[i] = (uint32_t)(v_is_unsigned64 || v > 0xFFFFFFFFLL ? 0xFFFFFFFFu : v < 0 ? 0 : v); break;
     case TRPX_I32: ((int32_t*)p)[i]  = (int32_t)(v_is_unsigned64 || v > 2147483647LL ? 2147483647 : v < -2147483648LL ? -2147483648LL : v); break;
     case TRPX_U64: ((uint64_t*)p)[i] = v_is_unsigned64 ? (uint64_t)v : (v < 0 ? 0 : (uint64_t)v); break;
+    /* non-integral output: begin[i] = double(std::uint64_t(bitr)) / double(std::int64_t(bitr)) (Terse.hpp:379-383) */
+    case ORACLE_F32: ((float*)p)[i]  = (float)(v_is_unsigned64 ? (double)(uint64_t)v : (double)v); break;
+    case ORACLE_F64: ((double*)p)[i] = v_is_unsigned64 ? (double)(uint64_t)v : (double)v; break;
     default:       ((int64_t*)p)[i]  = v_is_unsigned64 ? INT64_MAX : v; break;
     }
 }

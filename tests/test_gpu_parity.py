@@ -437,9 +437,10 @@ def test_converting_decode_cross_type_and_float(gpu, oracle):
             else:
                 di = np.iinfo(dst)
                 want = np.clip(px.astype(np.int64), di.min, di.max).astype(dst)
-                chk = np.stack([oracle.decode(stream[int(offs[f]):int(offs[f + 1])], n, dst, stream_signed=s_signed) for f in range(frames)])
-                assert (chk == want).all()
-            assert (got == want).all(), (src, dst)
+            # the oracle's own decode path into the same output type (float / double: Terse.hpp:379-383)
+            chk = np.stack([oracle.decode(stream[int(offs[f]):int(offs[f + 1])], n, dst, stream_signed=s_signed) for f in range(frames)])
+            assert (chk == want).all(), (src, dst)
+            assert (got == chk).all(), (src, dst)
     # the class surface: decode a u16 object into int32 / float64 containers
     from trpx_amd import Terse
     px = rng.randint(0, 60000, size=4000).astype(np.uint16)

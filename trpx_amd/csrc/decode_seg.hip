@@ -247,10 +247,11 @@ __device__ __forceinline__ uint64_t seg_shfl_up1(uint64_t v) {
 struct SegState {
     uint64_t* in;        // IN state of every segment
     uint64_t* out;       // OUT state
-    uint32_t* cnt;       // blocks counted; bit 31: the IN state is still the lane's own run guess ("strong")
+    uint32_t* cnt;       // blocks counted; bit 31: the IN state is still the lane's own run guess ("strong"); bit 30: IN changed, OUT / count are stale
     uint32_t* bnd;       // boundary B_j (X_j unless a run guess moved it)
-    uint32_t* base;      // blocks in front of the segment (k_seg_resolve)
     uint32_t* open;      // per wave: a link inside the wave is still open
+    uint32_t* wtot;      // per wave: blocks counted by its 64 segments
+    uint32_t* wbase;     // per wave: blocks in front of it (k_seg_resolve)
 };
 
 // Fix-point rounds of wave k of a frame (segments 64 k .. 64 k + 63).  `first`: no earlier launch has left states
@@ -270,11 +271,11 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
     const bool walks = j < jl;                                 // lane jl and the lanes behind it own no counted blocks
     uint64_t in = seg_pack(j * c.L, 0u), out = 0ull;
     uint32_t cnt = 0u, B = j * c.L;
-    bool strong = false, dirty = walks;
+    bool strong = false, dirty = walks;                        // dirty: (in, out) do not belong together yet -- the lane has to walk
     if (!first) {
         in = st.in[j]; out = st.out[j]; B = st.bnd[j];
         const uint32_t cs = st.cnt[j];
-        cnt = cs & 0x7FFFFFFFu; strong = (cs >> 31) != 0u; dirty = false;
+        cnt = cs & 0x3FFFFFFFu; strong = (cs >> 31) != 0u; dirty = ((cs >> 30) & 1u) != 0u && walks;   // (left dirty by a capped launch)
     } else if (__ballot(walks)) {                              // run-dominated streams: start inside a run
         const uint32_t oct = lane & ~7u, piece = lane & 7u;
 #pragma unroll
@@ -292,48 +293,54 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
     if (j == 0u) { in = 0ull; B = 0u; strong = false; }       // the frame starts with width 0 at bit 0 (Terse.hpp:359, :505)
     if (lane == 0u && k > 0u && !first) {
         const uint64_t ni = __hip_atomic_load(&st.out[j - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ni != in) { in = ni; dirty = walks; }
+        if (ni != in) { in = ni; strong = false; dirty = walks; }
     }
     uint32_t endB = (uint32_t)__shfl_down((int)B, 1, 64);
     if (lane == 63u) endB = (j + 1u) * c.L;
-    bool tent = false, conflict = false;
+    bool tent = false;
     uint64_t sav_in = 0ull, sav_out = 0ull, rej = ~0ull;
     uint32_t sav_cnt = 0u;
-    for (int iter = 0; iter < max_rounds; ++iter) {
-        if (!__ballot(dirty)) break;
+    for (int iter = 0;; ++iter) {
+        if (__ballot(dirty)) {
+            if (iter >= max_rounds) break;                     // capped: what is still dirty / open is left to the next launch or to k_seg_resolve
 #ifdef TRPX_SEG_STATS
-        if (lane == 0u) { atomicAdd(c.stat + 2, 1u); atomicAdd(c.stat + 4, (uint32_t)__builtin_popcountll(__ballot(dirty))); }
+            if (lane == 0u) { atomicAdd(c.stat + 2, 1u); atomicAdd(c.stat + 4, (uint32_t)__builtin_popcountll(__ballot(dirty))); }
 #endif
-        uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
-        bool bad = false;
-        seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
-        if (dirty) {
-            const uint64_t o = seg_pack(pos, w);
-            if (tent) {
-                if (o == sav_out) { out = o; cnt = n; strong = false; }          // merged: the predecessor's state is as good as mine
-                else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; }    // back to the run guess
-            } else { out = o; cnt = n; }
+            uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
+            bool bad = false;
+            seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
+            if (dirty) {
+                const uint64_t o = seg_pack(pos, w);
+                if (tent) {
+                    if (o == sav_out) { out = o; cnt = n; strong = false; }          // merged: the predecessor's state is as good as mine
+                    else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; }    // back to the run guess
+                } else { out = o; cnt = n; }
+            }
+            dirty = false; tent = false;
         }
+        // the links: who has to give up its IN state for its predecessor's OUT state?
         const uint64_t prev = seg_shfl_up1(out);
-        conflict = lane > 0u && j <= jl && prev != in;
+        const bool conflict = lane > 0u && j <= jl && prev != in;
         const uint64_t closed = __ballot(!conflict);
         const uint32_t first_open = ~closed ? (uint32_t)__builtin_ctzll(~closed) : 64u;
         const bool pred_ver = lane0_true && lane <= first_open;
         const bool pred_link = lane >= 2u ? ((closed >> (lane - 1u)) & 1ull) != 0ull : lane0_true;
         const bool trusted = !strong || !walks || pred_ver || pred_link;
-        tent = false; dirty = false;
         if (conflict && trusted) { in = prev; strong = false; dirty = walks; }
         else if (conflict && prev != rej) { sav_in = in; sav_out = out; sav_cnt = cnt; in = prev; tent = true; dirty = true; }
+        if (!__ballot(dirty)) break;
     }
-    // (links taken in the last round are closed once their lanes have walked; anything still open is reported)
+    if (tent) { in = sav_in; out = sav_out; cnt = sav_cnt; dirty = false; }             // (capped in the middle of a try: back to the guess)
+    // anything still dirty or open is reported; a dirty lane is walked first thing by the next call
     const uint64_t prev = seg_shfl_up1(out);
     const bool still_open = (lane > 0u && j <= jl && prev != in) || dirty;
     const uint64_t any_open = __ballot(still_open);
     st.in[j] = in;
-    st.cnt[j] = (walks ? cnt : 0u) | (strong ? 0x80000000u : 0u);
+    st.cnt[j] = (walks ? cnt & 0x3FFFFFFFu : 0u) | (strong ? 0x80000000u : 0u) | (dirty ? 0x40000000u : 0u);
     st.bnd[j] = B;
     __hip_atomic_store(&st.out[j], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 0u) st.open[k] = any_open ? 1u : 0u;
+    const uint32_t total = wave_inclusive_scan(walks ? cnt & 0x3FFFFFFFu : 0u);
+    if (lane == 63u) { st.open[k] = any_open ? 1u : 0u; st.wtot[k] = total; }
 }
 
 // Write pass of wave k: `base` = blocks in front of the lane's segment, `end` = the next lane's boundary.
@@ -370,7 +377,7 @@ __device__ __forceinline__ void seg_zero_widths(uint8_t* __restrict__ wf, uint32
 
 struct SegWs {            // carve of seg_workspace_bytes()
     uint64_t *in, *out;
-    uint32_t *cnt, *bnd, *base, *open, *fallback;
+    uint32_t *cnt, *bnd, *open, *wtot, *wbase, *fallback;
 };
 __host__ __device__ inline SegWs seg_carve(void* ws, size_t n_frames, uint32_t K) {
     const size_t segs = n_frames * (size_t)K * kWave;
@@ -379,14 +386,15 @@ __host__ __device__ inline SegWs seg_carve(void* ws, size_t n_frames, uint32_t K
     s.out = s.in + segs;
     s.cnt = reinterpret_cast<uint32_t*>(s.out + segs);
     s.bnd = s.cnt + segs;
-    s.base = s.bnd + segs;
-    s.open = s.base + segs;
-    s.fallback = s.open + n_frames * (size_t)K;
+    s.open = s.bnd + segs;
+    s.wtot = s.open + n_frames * (size_t)K;
+    s.wbase = s.wtot + n_frames * (size_t)K;
+    s.fallback = s.wbase + n_frames * (size_t)K;
     return s;
 }
 __device__ __forceinline__ SegState seg_state(const SegWs& w, uint64_t frame, uint32_t K) {
     const uint64_t so = frame * K * kWave;
-    return SegState{w.in + so, w.out + so, w.cnt + so, w.bnd + so, w.base + so, w.open + frame * K};
+    return SegState{w.in + so, w.out + so, w.cnt + so, w.bnd + so, w.open + frame * K, w.wtot + frame * K, w.wbase + frame * K};
 }
 
 // ---- one wavefront per frame (G = 64): rounds, prefix sum and write pass in one go ---------------------------------------
@@ -408,7 +416,7 @@ __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse
     seg_fixpoint(c, win, 0u, jl, true, true, 70, st);
     __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before the write pass stores widths
     const uint64_t in = st.in[lane];
-    const uint32_t cnt = st.cnt[lane] & 0x7FFFFFFFu;
+    const uint32_t cnt = st.cnt[lane] & 0x3FFFFFFFu;
     const uint64_t next_in = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)in, 1, 64) |
                              ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(in >> 32), 1, 64) << 32);
     const uint32_t end = (uint32_t)__shfl_down((int)st.bnd[lane], 1, 64);
@@ -496,25 +504,34 @@ __global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict
     const SegState st = seg_state(ws, frame, K);
     const uint32_t rerun_limit = 2u + K / 16u;
     uint32_t running = 0u, reruns = 0u;
-    for (uint32_t k = 0; k < K && 64u * k <= jl; ++k) {
-        bool need = __hip_atomic_load(&st.open[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        if (k > 0u) {
-            const uint64_t a = __hip_atomic_load(&st.in[64u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t b = __hip_atomic_load(&st.out[64u * k - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            need = need || a != b;
-        }
-        if (need) {
+    for (uint32_t k0 = 0; k0 < K && 64u * k0 <= jl; k0 += kWave) {            // 64 of the frame's waves per step, one per lane
+        const uint32_t kk = k0 + lane;
+        const bool valid = kk < K && 64u * kk <= jl;
+        for (uint32_t from = k0;;) {                                           // links at or behind wave `from` may have changed
+            bool need = false;
+            if (valid && kk >= from) {
+                need = __hip_atomic_load(&st.open[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (kk > 0u) {
+                    const uint64_t a = __hip_atomic_load(&st.in[64u * kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t b = __hip_atomic_load(&st.out[64u * kk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    need = need || a != b;
+                }
+            }
+            const uint64_t mask = __ballot(need);
+            if (!mask) break;
             if (++reruns > rerun_limit) {
                 if (lane == 0) ws.fallback[frame] = 1u;
                 return;
             }
+            const uint32_t k = k0 + (uint32_t)__builtin_ctzll(mask);           // the first open one: its predecessors are final
             seg_fixpoint(c, win, k, jl, false, true, 70, st);
             __builtin_amdgcn_s_waitcnt(0);
             __threadfence();
+            from = k + 1u;
         }
-        const uint32_t cnt = __hip_atomic_load(&st.cnt[64u * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7FFFFFFFu;
-        const uint32_t inc = wave_inclusive_scan(cnt);
-        st.base[64u * k + lane] = running + inc - cnt;
+        const uint32_t tot = valid ? __hip_atomic_load(&st.wtot[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t inc = wave_inclusive_scan(tot);
+        if (valid) st.wbase[kk] = running + inc - tot;
         running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
 }
@@ -535,19 +552,25 @@ __global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__
     const SegState st = seg_state(ws, frame, K);
     const uint32_t j = 64u * k + lane;
     const bool has_next = j + 1u < K * kWave;
-    seg_write(c, win, k, jl, st.in[j], has_next ? st.in[j + 1u] : 0ull, has_next ? st.bnd[j + 1u] : 0xFFFFFFFFu, st.base[j],
+    const uint32_t cnt = st.cnt[j] & 0x3FFFFFFFu;
+    const uint32_t base = st.wbase[k] + wave_inclusive_scan(cnt) - cnt;
+    seg_write(c, win, k, jl, st.in[j], has_next ? st.in[j + 1u] : 0ull, has_next ? st.bnd[j + 1u] : 0xFFFFFFFFu, base,
               widths + frame * g.n_blocks, tile_off + frame * g.n_tiles, c.limit / 8u, status);
 }
 
-// Segments per frame: a multiple of 64, about kSegTargetBlocks blocks each.
+// Segments per frame: a multiple of 64.  Frames of up to 32 K blocks (512 x 512: 21 846) are one wavefront -- rounds, prefix
+// sum and write pass in one launch, which is what the per-frame decoder's deferral needs; larger frames get segments of
+// about kSegTargetBlocks blocks, i.e. enough wavefronts to fill the GPU even for a handful of frames (eight 4096 x 4096
+// frames: 8 x 228 wavefronts; measured walk time for them with targets 320 / 160 / 96 / 64 blocks: 1.17 / 1.03 / 0.87 / 1.08 ms).
 uint32_t seg_waves_per_frame(const FrameGeom& g) {
-    constexpr uint64_t kSegTargetBlocks = 320;
+    static const uint64_t kSegTargetBlocks = getenv("TRPX_SEG_TARGET") ? (uint64_t)atoi(getenv("TRPX_SEG_TARGET")) : 96;
+    if (g.n_blocks <= 32768u) return 1;
     const uint64_t k = ((uint64_t)g.n_blocks + 32 * kSegTargetBlocks) / (64 * kSegTargetBlocks);
     return (uint32_t)(k ? k : 1);
 }
 size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     const size_t K = seg_waves_per_frame(g), segs = n_frames * K * kWave;
-    return align_up(segs * (8 + 8 + 4 + 4 + 4) + n_frames * K * 4 + n_frames * 4, 256);
+    return align_up(segs * (8 + 8 + 4 + 4) + n_frames * K * 12 + n_frames * 4, 256);
 }
 
 hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st);   // decode_fast.hip
