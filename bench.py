@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default: configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the informative legs (configs[3], noisy_u16, index decode): profiler passes see the headline kernels only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,9 +220,11 @@ def main():
         enc_ms = timed(lambda: codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e))
         dec_ms = timed(lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d))
         # walk-free decode with the encoder's optional decode index (not part of `value`)
-        enc_i = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e, index=True)
-        dec_idx_ms = timed(lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, status=st_d, index=enc_i.index))
-        assert int(st_d[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
+        dec_idx_ms = float("nan")
+        if not args.headline_only:
+            enc_i = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e, index=True)
+            dec_idx_ms = timed(lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, status=st_d, index=enc_i.index))
+            assert int(st_d[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
 
         # per-kernel durations: HIP events recorded by the library on the launch stream
         def stages(enc_fn, dec_fn, dec_names, n=reps):
@@ -279,6 +283,8 @@ def main():
         # configs[3] (informative, not part of `value`): 4096x4096 int32 frames with sparse peaks, 1 GPU
         c4 = {}
         try:
+            if args.headline_only:
+                raise RuntimeError("skipped (--headline-only)")
             n4, f4 = 4096 * 4096, 4
             px4 = codec.synth(np.int32, 0, f4, n4, device=dev)
             e4 = codec.encode(px4, index=True)
@@ -313,6 +319,8 @@ def main():
         # header every other block -- the worst case for the header chain (Terse.hpp:360-372), unlike synth-v1
         noisy = {}
         try:
+            if args.headline_only:
+                raise RuntimeError("skipped (--headline-only)")
             g = torch.Generator(device=dev)
             g.manual_seed(1)
             bg = torch.poisson(torch.full((frames, N_VALUES), 1.5, device=dev), generator=g).clamp_(0, 6).to(torch.int32)

@@ -210,7 +210,9 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 // A stream with an explicit header every few blocks costs this walker a step per header (10 x the time of a
                 // run-dominated frame); false chains merge quickly in such streams, so the frame goes to the
                 // position-parallel walk instead (decode_seg.hip).  Decided after super-steps 0, 3 and 11 on the width
-                // changes inside the super-step just walked (12 widths per lane, outside the step loop).
+                // changes inside the super-step just walked (12 widths per lane, outside the step loop).  (Probing the first 256
+                // blocks instead -- a second bound in the fast loop -- hands a header-dense frame over after 0.06 instead of
+                // 0.13 ms but cost every other stack 6-60 %: the loop bound became loop-variant.)
                 if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_b == (s + 1) * kStepBlocks && end_b < n_blocks) {
                     uint32_t changes = 0;
 #pragma unroll
