@@ -774,3 +774,48 @@ def test_device_resident_stack_read_frame_by_frame(gpu, oracle):
         assert rc in (_lib.OK, _lib.ERR_CORRUPT)
     finally:
         L.trpx_stack_close(h)
+
+
+def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):
+    """configs[4] (16 000 frames 512x512 u16, GPU g <- frames [2000 g, 2000 g + 2000)) on the one GPU of the test box:
+    the eight shards are encoded one after the other exactly as eight ranks would (same frame numbers, same calls), their
+    size messages go through the gather's scan kernel (trpx_gather_pack / trpx_gather_scan: ncclAllGather only moves
+    them), and the properties that do not need the CPU at full size are checked: every shard's stack size is what the
+    global offsets say, global offsets == running sum, sampled frames byte-identical to the oracle's single-frame encode,
+    every shard decodes pixel-identically with its slice of the GLOBAL offset table rebased to its shard."""
+    import torch
+    from trpx_amd import codec, _lib
+    L = _lib.lib()
+    n, per, world = 512 * 512, 2000, 8
+    ws = codec.Workspace(gpu)
+    msgs = torch.zeros(world * (per + 2), dtype=torch.int64, device=gpu)
+    totals, shards = [], []
+    px = None
+    for r in range(world):
+        px = codec.synth(np.uint16, r * per, per, n, device=gpu)
+        enc = codec.encode(px, workspace=ws)
+        torch.cuda.synchronize()
+        enc.check()
+        assert L.trpx_gather_pack(enc.frame_offsets.data_ptr(), per, per, enc.status.data_ptr(), msgs[r * (per + 2):].data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        totals.append(enc.total_bytes())
+        for f in (0, per - 1):                                               # the shard's first and last frame against the oracle
+            want = oracle.encode(px[f].cpu().numpy())[0]
+            a, b = int(enc.frame_offsets[f]), int(enc.frame_offsets[f + 1])
+            assert b - a == want.size and (enc.data[a:b].cpu().numpy() == want).all(), (r, f)
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, per, np.uint16, workspace=ws)
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16)), r
+        shards.append((enc.frame_offsets.clone(), enc.total_bytes()))
+        del enc, back
+    assert totals[0] == 203596114                                            # SURVEY.md 8 row d (frames 0..1999)
+    go = torch.zeros(world * per + 1, dtype=torch.int64, device=gpu)
+    pb = torch.zeros(2, dtype=torch.int32, device=gpu)
+    rb = torch.zeros(world, dtype=torch.int64, device=gpu)
+    assert L.trpx_gather_scan(msgs.data_ptr(), world, per, go.data_ptr(), pb.data_ptr(), rb.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(pb[0]) == 12 and int(go[0]) == 0 and int(go[-1]) == sum(totals)
+    bases = np.concatenate([[0], np.cumsum(totals)])
+    assert rb.cpu().numpy().tolist() == bases[:-1].tolist()
+    for r, (loc, tot) in enumerate(shards):
+        assert torch.equal(go[r * per: (r + 1) * per + 1] - int(bases[r]), loc), r
