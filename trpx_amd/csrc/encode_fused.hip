@@ -395,6 +395,7 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     __shared__ uint64_t s_excl_bits;       // bits of this frame before the tile
     __shared__ uint64_t s_base_bytes;      // first byte of this frame in the stack
     __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_halo;            // width of the block in front of the tile (wave 0 computes it, every wave needs it)
 
     const uint32_t tid = threadIdx.x;
 #define TRPX_STAMP(slot) do { if ((TRPX_DIAG(a) & 4u) && threadIdx.x == 0) a.stamps[((uint64_t)(blockIdx.z * kGridY + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -422,14 +423,18 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     int nb[kSub];
     const bool has_full = g.n_values >= (uint64_t)kBlock;
     const uint64_t max_first = has_full ? g.n_values - kBlock : 0;      // vector aligned: n_values % 4 == 0 on this path
-    uint32_t h[Raw<T>::dw];              // block b0-1 (never the frame's last: full), for the tile's first header
+    uint32_t h[Raw<T>::dw];              // block b0-1 (never the frame's last: full), for the tile's first header: wave 0 only
     if (has_full) {
 #pragma unroll
         for (int r = 0; r < kSub; ++r) {
             const uint64_t first = (uint64_t)(b0 + r * kThreads + tid) * kBlock;
             load_raw_nt<T>(fp + (first < max_first ? first : max_first), v[r]);
         }
-        load_raw_nt<T>(fp + (uint64_t)(b0 ? b0 - 1 : 0) * kBlock, h);
+        if (wave == 0) load_raw_nt<T>(fp + (uint64_t)(b0 ? b0 - 1 : 0) * kBlock, h);
+        else {
+#pragma unroll
+            for (int i = 0; i < Raw<T>::dw; ++i) h[i] = 0u;
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < kSub; ++r)
@@ -438,11 +443,11 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
 #pragma unroll
         for (int i = 0; i < Raw<T>::dw; ++i) h[i] = 0u;
     }
+    const uint32_t nb_tail = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);   // values of the frame's last block (scalar)
 #pragma unroll
     for (int r = 0; r < kSub; ++r) {
-        const uint32_t b = b0 + r * kThreads + tid;
-        const uint64_t first = (uint64_t)b * kBlock;
-        nb[r] = b < g.n_blocks ? (first + kBlock <= g.n_values ? kBlock : (int)(g.n_values - first)) : 0;
+        const uint32_t b1 = b0 + r * kThreads + tid + 1u;
+        nb[r] = b1 < g.n_blocks ? kBlock : (b1 == g.n_blocks ? (int)nb_tail : 0);
     }
     if (tid == 0) s_abort = 0;
     if (tid <= 32u) s_hdr[tid] = header_val(tid, tid + 1u) << (32u - header_len(tid, tid + 1u));
@@ -463,9 +468,14 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
         if (bp >= b0 && (bp - b0) % kThreads == tid) load_raw_partial<T>(fp + (uint64_t)bp * kBlock, (int)(g.n_values % kBlock), pv);
     }
     TRPX_STAMP(7);                                                       // loads issued
-    const uint32_t w_part = raw_width<T>(pv);
-    // width of the block before the tile's first block (w_{-1} = 0 at frame start, Terse.hpp:505)
-    const uint32_t tile_halo = b0 > 0 ? raw_width<T>(h) : 0u;           // every wave: it redoes the piece scan itself
+    uint32_t w_part = 0u;
+    if (last_tile_of_frame && g.n_values % kBlock) w_part = raw_width<T>(pv);             // (workgroup-uniform branch)
+    // width of the block before the tile's first block (w_{-1} = 0 at frame start, Terse.hpp:505): wave 0 computes it,
+    // every wave reads it behind barrier #1 (each redoes the piece scan itself)
+    if (wave == 0) {
+        const uint32_t hw0 = b0 > 0 ? raw_width<T>(h) : 0u;
+        if (lane == 0) s_halo = hw0;
+    }
     // Lanes 1..63 get the previous block's width from their neighbour; lane 0's header depends on the
     // previous wavefront's last width, so it is left out of the scan here and added after barrier #1.
     uint32_t wmax = 0;
@@ -504,6 +514,7 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
 
     // Every wave, lanes 0..15: lane-0 header of each of the 16 (round, wave) pieces -- it depends on the
     // previous piece's last width -- then the exclusive scan of the piece sizes (tile-relative bit offsets).
+    const uint32_t tile_halo = s_halo;
     uint32_t rb[kSub + 1];               // tile-relative bit where round r starts; rb[kSub] = tile bits
     uint32_t off[kSub], wp[kSub];        // tile-relative bit position of this lane's block; its w_{b-1}
     {
