@@ -1,3 +1,5 @@
+#include <stddef.h>
+#include <utility>
 // Single-pass TERSE encoder for gfx950 (CDNA4): pixels are read from HBM exactly once and every
 // stream byte is written exactly once (algorithmic traffic N*sizeof(T) + S per frame).
 // Replaces jpa::Terse::f_compress (reference include/Terse.hpp:500-549) and the Bit_pointer.hpp
@@ -37,7 +39,7 @@ namespace trpx {
 // 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms; 4096^2 i32:
 // 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
 template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
-template <typename T> constexpr int fused_occupancy() { return sizeof(T) <= 2 ? 6 : 4; }   // workgroups per CU (LDS image + VGPR budget)
+template <typename T> constexpr int fused_occupancy() { return sizeof(T) <= 2 ? 7 : 4; }   // workgroups per CU (LDS image + VGPR budget)
 // Every wait on another tile is bounded in WALL time: a poll loop gives up kWaitTicks of the 100 MHz realtime counter
 // after it started (0.25 s; the whole 2000-frame launch takes 0.3 ms, so this only ever triggers when tiles do not
 // make progress at all), checked every 64 polls.  The caller then sees TRPX_ERR_TIMEOUT in status[0]
@@ -358,8 +360,10 @@ __device__ __forceinline__ void pack_payload_generic(uint32_t* __restrict__ stag
     }
 }
 
+// The LDS image holds fused_phase_rounds() rounds of worst-case blocks (+ a carried dword); larger tiles take two phases.
+template <typename T> constexpr int fused_phase_rounds() { return (sub_tiles<T>() + 1) / 2; }
 template <typename T>
-constexpr int fused_stage_dwords() { return sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 8; }   // worst-case tile
+constexpr int fused_stage_dwords() { return fused_phase_rounds<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 12; }
 
 struct FusedArgs {
     FrameGeom g;
@@ -381,6 +385,13 @@ struct FusedArgs {
     uint64_t* stamps;              // [tiles][8]
 };
 
+// Arguments that are only needed behind the packing (the tile's place in the stack, the flush) are fetched from the
+// kernel-argument segment where they are used instead of living in SGPRs from the kernel's first instruction on: `kb` is
+// the segment's base made opaque at that point (a scalar load of a few dwords per tile against ~20 SGPRs less to spill
+// around the specialised packing bodies).  Layout: `pixels` at byte 0, the FusedArgs struct at byte 8.
+typedef const char __attribute__((address_space(4)))* karg_ptr;
+#define TRPX_KARG(kb, field) (*reinterpret_cast<const decltype(FusedArgs::field) __attribute__((address_space(4)))*>((kb) + 8 + offsetof(FusedArgs, field)))
+
 template <typename T>
 __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused(const T* __restrict__ pixels, FusedArgs a) {
     constexpr int kSub = sub_tiles<T>();
@@ -395,6 +406,7 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     __shared__ uint64_t s_excl_bits;       // bits of this frame before the tile
     __shared__ uint64_t s_base_bytes;      // first byte of this frame in the stack
     __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_carry;           // two-phase tiles: phase 0's bits of the output dword the phases share
     __shared__ uint32_t s_halo;            // width of the block in front of the tile (wave 0 computes it, every wave needs it)
 
     const uint32_t tid = threadIdx.x;
@@ -553,41 +565,50 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     // them -- an atomicMax per wave on one status word meant ~4000 same-address atomics (~11 ns each, serialised) from
     // the first wave of tiles, and every wave's next s_waitcnt vmcnt sat behind its own: a ~25 us stall per launch.
     // ---- pack into the tile-relative LDS image, look back meanwhile, flush with a funnel shift ---------
-    {
+    // The image holds kPhaseRounds rounds of worst-case blocks (half a worst-case tile: 13 KB for 16-bit pixels, which is
+    // what lets a seventh workgroup onto the CU).  A tile that needs more -- more than ~100 bits per block on average -- is
+    // packed and flushed in TWO phases (rounds [0, kPhaseRounds), then the rest): phase 1's image starts at the output
+    // dword in which phase 0 ended, and the bits phase 0 left in that dword are carried into it.
+    constexpr int kPhaseRounds = fused_phase_rounds<T>();
+    constexpr uint32_t kCapBits = (uint32_t)kPhaseRounds * kThreads * max_block_bits<T>();
+    const bool two_phase = tile_total > kCapBits;                         // (workgroup-uniform)
+    uint64_t p0 = 0, p_end = 0;                                          // absolute bit range of the tile (known behind barrier #2)
+    uint64_t img_p0 = 0;                                                 // absolute bit of image bit 0 in the current phase
+    uint32_t bias = 0;                                                   // tile-relative bit of image bit 0
+    bool writable = false;
 #ifndef TRPX_ABLATE
 #define TRPX_ABLATE 0
 #endif
-        // Full blocks: header + payload as ONE bit string, one pass per distinct width present in the wavefront (w = 0:
-        // the header alone), each with static shifts.  The frame's partial last block goes the generic way.
 #define TRPX_WSTAMP(slot) do { if ((TRPX_DIAG(a) & 8u) && lane == 0 && tile < 4096) a.stamps[tile * 32 + wave * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-        TRPX_WSTAMP(0);
-#pragma unroll
-        for (int r = 0; r < kSub; ++r) {
-            const uint32_t pos = off[r];
-            const uint32_t hl = hlr[r];                                  // (lane 0: from the piece fix-up)
-            const uint32_t wr = w[r];
-            const uint32_t hv_top = wr == wp[r] ? 0x80000000u : s_hdr[wr];   // header code, top aligned (Terse.hpp:517-535)
-            const bool full = nb[r] == kBlock;
-            if (nb[r] && !full && !(TRPX_ABLATE & 2)) {
-                const uint64_t hx = (uint64_t)(hv_top >> (32u - hl)) << (pos & 31u);
-                atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
-                if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
-                if (wr) pack_payload_generic<T>(s_stage, pos + hl, wr, nb[r], pv);
-            }
-            uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(full);
-            while (todo) {
-                const int l0 = __builtin_ctzll(todo);
-                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wr, l0);
-                const bool mine = full && wr == w0;
-#pragma unroll
-                for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));   // keep the bodies out of LICM's reach
-                if (mine) PackDispatch<T, 0, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, hv_top, w0, v[r]);
-                todo &= ~__ballot(mine);
-            }
-            TRPX_WSTAMP(1 + r);
+    // Full blocks: header + payload as ONE bit string, one pass per distinct width present in the wavefront (w = 0:
+    // the header alone), each with static shifts.  The frame's partial last block goes the generic way.
+    auto pack_round = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const uint32_t pos = off[r] - bias;
+        const uint32_t hl = hlr[r];                                      // (lane 0: from the piece fix-up)
+        const uint32_t wr = w[r];
+        const uint32_t hv_top = wr == wp[r] ? 0x80000000u : s_hdr[wr];   // header code, top aligned (Terse.hpp:517-535)
+        const bool full = nb[r] == kBlock;
+        if (nb[r] && !full && !(TRPX_ABLATE & 2)) {
+            const uint64_t hx = (uint64_t)(hv_top >> (32u - hl)) << (pos & 31u);
+            atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
+            if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
+            if (wr) pack_payload_generic<T>(s_stage, pos + hl, wr, nb[r], pv);
         }
-
-        // cross-tile prefixes (decoupled look-back), after this wave's share of the packing
+        uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(full);
+        while (todo) {
+            const int l0 = __builtin_ctzll(todo);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wr, l0);
+            const bool mine = full && wr == w0;
+#pragma unroll
+            for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));       // keep the bodies out of LICM's reach
+            if (mine) PackDispatch<T, 0, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, hv_top, w0, v[r]);
+            todo &= ~__ballot(mine);
+        }
+        TRPX_WSTAMP(1 + r);
+    };
+    // cross-tile prefixes (decoupled look-back), after this wave's share of the packing
+    auto look_back = [&]() {
         if (wave == 0) {
             uint64_t excl = 0;
             bool ok = true;
@@ -621,99 +642,144 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
             }
             if (lane == 0) { s_base_bytes = base; if (!ok) s_abort = 1; }
         }
-    }
-    __syncthreads();                                                     // #2: tile packed, prefixes known
-    TRPX_STAMP(3);
-    const bool aborted = s_abort != 0;
-    const uint64_t excl_bits = s_excl_bits, base_bytes = s_base_bytes;
-    const uint64_t frame_size = 1 + (excl_bits + tile_total) / 8;        // valid for the frame's last tile
-    if (last_tile_of_frame && tid == 0 && !aborted) {
-        st_desc(a.frame_pref + frame, kPrefFlag | (base_bytes + frame_size));
-        a.frame_offsets[frame + 1] = base_bytes + frame_size;
-        if (frame == 0) a.frame_offsets[0] = 0;
-        if (frame + 1 == a.n_frames && align_up(base_bytes + frame_size, 4) > a.out_capacity)
-            atomicMax(&a.status[0], 3u);                                 // TRPX_ERR_CAPACITY
-    }
-    if (aborted) {
-        if (tid == 0) atomicMax(&a.status[0], 7u);                       // look-back timeout
-        return;
-    }
-    if (a.idx_group_off && tid < (uint32_t)kSub && b0 + tid * kThreads < g.n_blocks) {
-        uint32_t rbv = 0;
-#pragma unroll
-        for (int r = 0; r < kSub; ++r) rbv = tid == (uint32_t)r ? rb[r] : rbv;
-        a.idx_group_off[(uint64_t)frame * g.n_tiles + (uint64_t)t * kSub + tid] = excl_bits + rbv;
-    }
-    const uint64_t p0 = 8 * base_bytes + excl_bits;                      // absolute bit of the tile's first bit
-    // bits this tile must materialise: its blocks, plus the frame's pad up to the byte S_f
-    const uint64_t p_end = last_tile_of_frame ? 8 * (base_bytes + frame_size) : p0 + tile_total;
-    const bool writable = align_up((p_end + 7) / 8, 4) <= a.out_capacity;   // sizes-only query / too small: no stores
-    const uint32_t s0 = (uint32_t)(p0 & 31), sh = (32u - s0) & 31u;
-    const bool head_pending = s0 != 0;                                   // first dword also holds the previous tile's bits
-    const uint64_t d_first = p0 >> 5, d_last = p_end >> 5;
-
-    // ---- tile boundary dwords ---------------------------------------------------------------------------
-    // A dword that straddles two tiles (or frames) is written by nobody here: both sides OR their bits into the
-    // boundary's exchange word {bit 63: head side there, bit 62: tail side there, low 32: the bits} with a
-    // fire-and-forget atomic and the head side records the dword's index; k_stitch (a ~44 000-thread kernel
-    // right behind this one) stores the merged dwords.  Nothing in this kernel waits for another tile's data.
-    const int32_t k_first = head_pending ? -1 : 0;
-    const uint32_t n_out = (uint32_t)(d_last - d_first);
-    const bool completed_first = d_last > d_first;                       // tile finished at least its first dword
-    const bool is_last_tile = tile + 1 == (uint64_t)a.n_frames * a.tiles_per_frame;
-    if (tid == 0) {
-        const int32_t kt = k_first + (int32_t)n_out;
-        const uint32_t tail_bits = (p_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], s_stage[kt], sh) : 0u;
-        if (head_pending) {                                              // our share of dword d_first (a tile that does not
-            const uint32_t head_bits = __builtin_amdgcn_alignbit(s_stage[0], 0u, sh);   // complete it: all of its bits)
-            __hip_atomic_fetch_or(a.tail_desc + tile, kHeadFlag | head_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Behind the barrier that follows the look-back: the tile's place in the stack.  Returns false if a wait gave up.
+    auto place_tile = [&]() -> bool {
+        karg_ptr kb = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kb));
+        const bool aborted = s_abort != 0;
+        const uint64_t excl_bits = s_excl_bits, base_bytes = s_base_bytes;
+        const uint64_t frame_size = 1 + (excl_bits + tile_total) / 8;        // valid for the frame's last tile
+        if (last_tile_of_frame && tid == 0 && !aborted) {
+            st_desc(TRPX_KARG(kb, frame_pref) + frame, kPrefFlag | (base_bytes + frame_size));
+            TRPX_KARG(kb, frame_offsets)[frame + 1] = base_bytes + frame_size;
+            if (frame == 0) TRPX_KARG(kb, frame_offsets)[0] = 0;
+            if (frame + 1 == TRPX_KARG(kb, n_frames) && align_up(base_bytes + frame_size, 4) > TRPX_KARG(kb, out_capacity))
+                atomicMax(&TRPX_KARG(kb, status)[0], 3u);                                 // TRPX_ERR_CAPACITY
         }
-        uint32_t wm = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wm = (s_wfl[i] >> 24) > wm ? (s_wfl[i] >> 24) : wm;
-        a.bnd_pos[tile] = (head_pending ? d_first : 0ull) | ((uint64_t)wm << kWmaxShift);
-        if ((p_end & 31) != 0 && (completed_first || !head_pending)) {   // our share of dword d_last
-            if (is_last_tile) { if (writable) __builtin_nontemporal_store(tail_bits, a.out32 + d_last); }
-            else __hip_atomic_fetch_or(a.tail_desc + tile + 1, kTailFlag | tail_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (aborted) {
+            if (tid == 0) atomicMax(&TRPX_KARG(kb, status)[0], 7u);                       // look-back timeout
+            return false;
         }
-    }
-
-    // ---- flush: global dword d_first + j = {image[k+1], image[k]} >> sh, k = j - (s0 != 0) -------------------
-    // 16-byte groups: one thread turns two aligned ds_read_b128 into one 16-byte aligned non-temporal store (the
-    // image-side misalignment m is tile-uniform: four specialised bodies behind scalar branches).  The <= 7 dwords in
-    // front of / behind the aligned groups go one per thread.
-    if (!(TRPX_ABLATE & 4) && writable) {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        uint32_t al = (0u - ((uint32_t)((uintptr_t)a.out32 >> 2) + (uint32_t)d_first)) & 3u;
-        if (head_pending && al == 0) al = 4;                              // dword 0 is k_stitch's: keep it out of the groups
-        al = al < n_out ? al : n_out;
-        const uint32_t n4 = (n_out - al) >> 2, rest0 = al + 4 * n4;
-        if (tid < al + (n_out - rest0)) {
-            const uint32_t j = tid < al ? tid : rest0 + (tid - al);
-            if (!(j == 0 && head_pending)) {
-                const int32_t k = k_first + (int32_t)j;                   // k = -1: the pad dword
-                __builtin_nontemporal_store(__builtin_amdgcn_alignbit(s_stage[k + 1], s_stage[k], sh), a.out32 + d_first + j);
+        if (TRPX_KARG(kb, idx_group_off) && tid < (uint32_t)kSub && b0 + tid * kThreads < g.n_blocks) {
+            uint32_t rbv = 0;
+#pragma unroll
+            for (int r = 0; r < kSub; ++r) rbv = tid == (uint32_t)r ? rb[r] : rbv;
+            TRPX_KARG(kb, idx_group_off)[(uint64_t)frame * g.n_tiles + (uint64_t)t * kSub + tid] = excl_bits + rbv;
+        }
+        p0 = 8 * base_bytes + excl_bits;                                     // absolute bit of the tile's first bit
+        // bits this tile must materialise: its blocks, plus the frame's pad up to the byte S_f
+        p_end = last_tile_of_frame ? 8 * (base_bytes + frame_size) : p0 + tile_total;
+        writable = align_up((p_end + 7) / 8, 4) <= TRPX_KARG(kb, out_capacity);           // sizes-only query / too small: no stores
+        img_p0 = p0;
+        return true;
+    };
+    // The image's bits [img_p0, q_end) -> memory.  first: the tile's first phase (records the boundary bookkeeping);
+    // carry_out: not the tile's last phase (the bits of the last, shared output dword stay in s_carry).
+    auto flush = [&](bool first, bool carry_out, uint64_t q_end) {
+        karg_ptr kb = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kb));
+        uint32_t* const out32 = TRPX_KARG(kb, out32);
+        uint64_t* const tail_desc = TRPX_KARG(kb, tail_desc);
+        const uint32_t s0 = (uint32_t)(img_p0 & 31), sh = (32u - s0) & 31u;
+        const bool head_pending = s0 != 0;                                   // first dword also holds the previous tile's bits
+        const uint64_t d_first = img_p0 >> 5, d_last = q_end >> 5;
+        // ---- tile boundary dwords ---------------------------------------------------------------------------
+        // A dword that straddles two tiles (or frames) is written by nobody here: both sides OR their bits into the
+        // boundary's exchange word {bit 63: head side there, bit 62: tail side there, low 32: the bits} with a
+        // fire-and-forget atomic and the head side records the dword's index; k_stitch (a ~44 000-thread kernel
+        // right behind this one) stores the merged dwords.  Nothing in this kernel waits for another tile's data.
+        // (A dword that straddles the two PHASES of one tile is carried into the second phase's image instead.)
+        const int32_t k_first = head_pending ? -1 : 0;
+        const uint32_t n_out = (uint32_t)(d_last - d_first);
+        const bool completed_first = d_last > d_first;                       // finished at least its first dword
+        const bool is_last_tile = tile + 1 == (uint64_t)TRPX_KARG(kb, n_frames) * TRPX_KARG(kb, tiles_per_frame);
+        if (tid == 0) {
+            const int32_t kt = k_first + (int32_t)n_out;
+            const uint32_t tail_bits = (q_end & 31) ? __builtin_amdgcn_alignbit(s_stage[kt + 1], s_stage[kt], sh) : 0u;
+            if (head_pending) {                                              // our share of dword d_first (a tile that does not
+                const uint32_t head_bits = __builtin_amdgcn_alignbit(s_stage[0], 0u, sh);   // complete it: all of its bits)
+                __hip_atomic_fetch_or(tail_desc + tile, kHeadFlag | head_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (first) {
+                uint32_t wm = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wm = (s_wfl[i] >> 24) > wm ? (s_wfl[i] >> 24) : wm;
+                TRPX_KARG(kb, bnd_pos)[tile] = (head_pending ? d_first : 0ull) | ((uint64_t)wm << kWmaxShift);
+            }
+            if (carry_out) s_carry = tail_bits;                              // this phase's share of dword d_last -> next image
+            else if ((q_end & 31) != 0 && (completed_first || !head_pending)) {   // our share of dword d_last
+                if (is_last_tile) { if (writable) __builtin_nontemporal_store(tail_bits, out32 + d_last); }
+                else __hip_atomic_fetch_or(tail_desc + tile + 1, kTailFlag | tail_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        const uint32_t kk0 = (uint32_t)(k_first + 1) + al;               // s_stage_pad index of the first group's low dword
-        const uint32_t m = kk0 & 3u;
-        const u4* pad4 = reinterpret_cast<const u4*>(s_stage_pad) + (kk0 >> 2);
-        u4* dst = reinterpret_cast<u4*>(a.out32 + d_first + al);
+        // ---- global dword d_first + j = {image[k+1], image[k]} >> sh, k = j - (s0 != 0) --------------------------
+        // 16-byte groups: one thread turns two aligned ds_read_b128 into one 16-byte aligned non-temporal store (the
+        // image-side misalignment m is tile-uniform: four specialised bodies behind scalar branches).  The <= 7 dwords in
+        // front of / behind the aligned groups go one per thread.
+        if (!(TRPX_ABLATE & 4) && writable) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            uint32_t al = (0u - ((uint32_t)((uintptr_t)out32 >> 2) + (uint32_t)d_first)) & 3u;
+            if (head_pending && al == 0) al = 4;                              // dword 0 is k_stitch's: keep it out of the groups
+            al = al < n_out ? al : n_out;
+            const uint32_t n4 = (n_out - al) >> 2, rest0 = al + 4 * n4;
+            if (tid < al + (n_out - rest0)) {
+                const uint32_t j = tid < al ? tid : rest0 + (tid - al);
+                if (!(j == 0 && head_pending)) {
+                    const int32_t k = k_first + (int32_t)j;                   // k = -1: the pad dword
+                    __builtin_nontemporal_store(__builtin_amdgcn_alignbit(s_stage[k + 1], s_stage[k], sh), out32 + d_first + j);
+                }
+            }
+            const uint32_t kk0 = (uint32_t)(k_first + 1) + al;               // s_stage_pad index of the first group's low dword
+            const uint32_t m = kk0 & 3u;
+            const u4* pad4 = reinterpret_cast<const u4*>(s_stage_pad) + (kk0 >> 2);
+            u4* dst = reinterpret_cast<u4*>(out32 + d_first + al);
 #define TRPX_FLUSH_GROUPS(M)                                                                                   \
-        for (uint32_t gq = tid; gq < n4; gq += kThreads) {                                                     \
-            const u4 A = pad4[gq], B = pad4[gq + 1];                                                           \
-            const uint32_t e[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};                                    \
-            u4 x;                                                                                              \
-            x.x = __builtin_amdgcn_alignbit(e[M + 1], e[M + 0], sh);                                           \
-            x.y = __builtin_amdgcn_alignbit(e[M + 2], e[M + 1], sh);                                           \
-            x.z = __builtin_amdgcn_alignbit(e[M + 3], e[M + 2], sh);                                           \
-            x.w = __builtin_amdgcn_alignbit(e[M + 4], e[M + 3], sh);                                           \
-            __builtin_nontemporal_store(x, dst + gq);                                                          \
-        }
-        if (m == 0) { TRPX_FLUSH_GROUPS(0) } else if (m == 1) { TRPX_FLUSH_GROUPS(1) }
-        else if (m == 2) { TRPX_FLUSH_GROUPS(2) } else { TRPX_FLUSH_GROUPS(3) }
+            for (uint32_t gq = tid; gq < n4; gq += kThreads) {                                                 \
+                const u4 A = pad4[gq], B = pad4[gq + 1];                                                       \
+                const uint32_t e[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};                                \
+                u4 x;                                                                                          \
+                x.x = __builtin_amdgcn_alignbit(e[M + 1], e[M + 0], sh);                                       \
+                x.y = __builtin_amdgcn_alignbit(e[M + 2], e[M + 1], sh);                                       \
+                x.z = __builtin_amdgcn_alignbit(e[M + 3], e[M + 2], sh);                                       \
+                x.w = __builtin_amdgcn_alignbit(e[M + 4], e[M + 3], sh);                                       \
+                __builtin_nontemporal_store(x, dst + gq);                                                      \
+            }
+            if (m == 0) { TRPX_FLUSH_GROUPS(0) } else if (m == 1) { TRPX_FLUSH_GROUPS(1) }
+            else if (m == 2) { TRPX_FLUSH_GROUPS(2) } else { TRPX_FLUSH_GROUPS(3) }
 #undef TRPX_FLUSH_GROUPS
+        }
+    };
+
+    TRPX_WSTAMP(0);
+    // rounds [0, kPhaseRounds)
+    [&]<int... R>(std::integer_sequence<int, R...>) { (pack_round(std::integral_constant<int, R>{}), ...); }(std::make_integer_sequence<int, kPhaseRounds>{});
+    if (two_phase) {
+        // the image is full: the tile's place has to be known now, its first half leaves, the second half gets a fresh
+        // image whose bit 0 is bit 0 of the output dword the halves share
+        look_back();
+        __syncthreads();
+        if (!place_tile()) return;
+        flush(true, true, p0 + rb[kPhaseRounds]);
+        const uint64_t d_last = (p0 + rb[kPhaseRounds]) >> 5;
+        __syncthreads();                                                     // every reader of the image is through
+        {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4* z = reinterpret_cast<u4*>(s_stage_pad);
+            for (int i = (int)tid; i < kStage4; i += kThreads) z[i] = (u4)(0u);
+        }
+        __syncthreads();
+        if (tid == 0 && s_carry) atomicOr(&s_stage[0], s_carry);
+        img_p0 = 32 * d_last;
+        bias = (uint32_t)(img_p0 - p0);
     }
+    // rounds [kPhaseRounds, kSub)
+    [&]<int... R>(std::integer_sequence<int, R...>) { (pack_round(std::integral_constant<int, kPhaseRounds + R>{}), ...); }(std::make_integer_sequence<int, kSub - kPhaseRounds>{});
+    if (!two_phase) look_back();
+    __syncthreads();                                                         // #2: tile packed, prefixes known
+    TRPX_STAMP(3);
+    if (!two_phase && !place_tile()) return;
+    flush(!two_phase, false, p_end);
     TRPX_STAMP(4);
     if ((TRPX_DIAG(a) & 4u) && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.stamps[tile * 8 + 6] = xcc; }
 }
