@@ -77,7 +77,7 @@ public:
     /// Copy-constructible like the reference's class (the device-side copy of the stack is not shared); not assignable.
     Terse(Terse const& o)
         : d_signed(o.d_signed), d_block(o.d_block), d_size(o.d_size), d_prolix_bits(o.d_prolix_bits), d_dim(o.d_dim),
-          d_terse_data(o.d_terse_data), d_frame_sizes(o.d_frame_sizes) {}
+          d_terse_data(o.d_terse_data), d_frame_sizes(o.d_frame_sizes), d_group_states(o.d_group_states) {}
     Terse& operator=(Terse const&) = delete;
     ~Terse() { f_drop_stack(); }
 
@@ -138,7 +138,7 @@ public:
         if (!d_stack) {
             std::vector<std::uint64_t> offs(d_frame_sizes.size() + 1, 0);
             for (std::size_t f = 0; f < d_frame_sizes.size(); ++f) offs[f + 1] = offs[f] + d_frame_sizes[f];
-            detail::check(trpx_stack_open(&d_stack, d_signed, d_terse_data.data(), d_terse_data.size(), offs.data(), d_size,
+            detail::check(trpx_stack_open(&d_stack, d_signed, d_terse_data.data(), d_terse_data.size(), offs.data(), f_states(), d_size,
                                           d_frame_sizes.size(), d_block, 0, -1), "Terse::prolix");
         }
         detail::check(trpx_stack_read(d_stack, frame, detail::out_dtype_of<V>(), dst), "Terse::prolix");
@@ -154,8 +154,8 @@ public:
         if (d_frame_sizes.empty()) return;
         std::vector<std::uint64_t> offs(d_frame_sizes.size() + 1, 0);
         for (std::size_t f = 0; f < d_frame_sizes.size(); ++f) offs[f + 1] = offs[f] + d_frame_sizes[f];
-        detail::check(trpx_decode_host(d_signed, detail::out_dtype_of<V>(), d_terse_data.data(), d_terse_data.size(), offs.data(),
-                                       d_size, d_frame_sizes.size(), d_block, out, -1), "Terse::prolix_all");
+        detail::check(trpx_decode_host_grouped(d_signed, detail::out_dtype_of<V>(), d_terse_data.data(), d_terse_data.size(), offs.data(),
+                                               f_states(), d_size, d_frame_sizes.size(), d_block, out, -1), "Terse::prolix_all");
     }
 
     std::size_t size() const { return d_size; }                                   // Terse.hpp:396
@@ -174,10 +174,14 @@ public:
     std::vector<std::size_t> const& frame_sizes() const { return d_frame_sizes; }
     std::vector<std::uint8_t> const& data() const { return d_terse_data; }
 
+    /// True if the object knows the chain state at every 256th block of every frame (read from a file written with
+    /// frame_index = true, or computed by that write): its frames are then expanded without any header walk.
+    bool has_group_index() const { return f_states() != nullptr; }
+
     /// XML-ish header + raw stack (Terse.hpp:454-474), byte-identical header text.  frame_index = true adds the
-    /// frame_sizes attribute: the reference reader ignores it, this reader then needs no
-    /// device walk to locate the frames.
-    void write(std::ostream& ostream, bool frame_index = false) const {
+    /// frame_sizes and group_bit_offsets attributes: the reference reader ignores them, this
+    /// reader then needs neither a device walk to locate the frames nor one to expand them.
+    void write(std::ostream& ostream, bool frame_index = false) {
         trpx_header h{};
         h.prolix_bits = d_prolix_bits;
         h.is_signed = d_signed;
@@ -187,10 +191,22 @@ public:
         h.number_of_frames = d_frame_sizes.size();
         h.n_dims = (unsigned)std::min<std::size_t>(d_dim.size(), 8);
         for (unsigned i = 0; i < h.n_dims; ++i) h.dims[i] = d_dim[i];
-        std::vector<char> buf(512 + (frame_index ? 21 * d_frame_sizes.size() : 0));
         std::vector<std::uint64_t> sizes(d_frame_sizes.begin(), d_frame_sizes.end());
-        const std::size_t n = frame_index ? trpx_header_format_indexed(&h, sizes.data(), sizes.size(), buf.data(), buf.size())
-                                          : trpx_header_format(&h, buf.data(), buf.size());
+        const std::size_t groups = frame_index ? trpx_group_count(d_size, d_block) : 0;      // 0: block != 12 (no group index)
+        if (groups && d_group_states.size() != groups * sizes.size() && !sizes.empty()) {
+            std::vector<std::uint64_t> offs(sizes.size() + 1, 0);
+            for (std::size_t f = 0; f < sizes.size(); ++f) offs[f + 1] = offs[f] + sizes[f];
+            d_group_states.assign(groups * sizes.size(), 0);
+            const unsigned max_bits = d_prolix_bits <= 8 ? 8 : d_prolix_bits <= 16 ? 16 : 32;
+            detail::check(trpx_group_states_host(d_terse_data.data(), d_terse_data.size(), offs.data(), d_size, sizes.size(), d_block,
+                                                 max_bits, d_group_states.data(), -1), "Terse::write");
+        }
+        const bool with_groups = groups && d_group_states.size() == groups * sizes.size();
+        std::vector<char> buf(512 + (frame_index ? 21 * d_frame_sizes.size() + (with_groups ? 16 * d_group_states.size() : 0) : 0));
+        const std::size_t n = !frame_index ? trpx_header_format(&h, buf.data(), buf.size())
+                              : with_groups ? trpx_header_format_grouped(&h, sizes.data(), sizes.size(), d_group_states.data(),
+                                                                         d_group_states.size(), buf.data(), buf.size())
+                                            : trpx_header_format_indexed(&h, sizes.data(), sizes.size(), buf.data(), buf.size());
         ostream.write(buf.data(), (std::streamsize)n);
         ostream.write(reinterpret_cast<const char*>(d_terse_data.data()), (std::streamsize)d_terse_data.size());
         ostream.flush();
@@ -205,6 +221,12 @@ private:
     std::vector<std::uint8_t> d_terse_data;
     std::vector<std::size_t> d_frame_sizes;
     trpx_stack* d_stack = nullptr;                     // the stack on the device, for prolix(it, frame); dropped when frames are added
+    std::vector<std::uint64_t> d_group_states;         // chain state at every 256th block of every frame (row f1), or empty
+
+    const std::uint64_t* f_states() const {
+        const std::size_t groups = trpx_group_count(d_size, d_block);
+        return groups && !d_frame_sizes.empty() && d_group_states.size() == groups * d_frame_sizes.size() ? d_group_states.data() : nullptr;
+    }
 
     void f_drop_stack() {
         if (d_stack) trpx_stack_close(d_stack);
@@ -215,6 +237,7 @@ private:
     void f_compress(Iterator data, std::size_t n_frames) {                        // Terse.hpp:500-549 -> device
         using V = typename std::iterator_traits<Iterator>::value_type;
         f_drop_stack();
+        d_group_states.clear();
         if constexpr (sizeof(V) == 8) {
             // 64-bit integers (what src/terse.cpp:120-123 makes of float / double images): the stream of values that fit
             // 32 bits is the same whatever the container's type, so they are narrowed here; wider values are refused --
@@ -299,6 +322,11 @@ private:
             detail::check(trpx_frame_offsets_host(d_terse_data.data(), d_terse_data.size(), d_size, h.number_of_frames,
                                                   d_block, max_bits, offs.data(), -1), "Terse(std::ifstream&)");
             for (std::size_t f = 0; f < h.number_of_frames; ++f) d_frame_sizes.push_back(std::size_t(offs[f + 1] - offs[f]));
+        }
+        const std::size_t groups = trpx_group_count(d_size, d_block);               // row f1: group states, if the file has them
+        if (groups && groups * d_frame_sizes.size() < (std::size_t(1) << 32)) {
+            std::vector<std::uint64_t> st(groups * d_frame_sizes.size());
+            if (trpx_header_group_states(blob.data(), off, st.data(), st.size()) == st.size()) d_group_states.swap(st);   // (checked on the device when used)
         }
     }
 };

@@ -238,18 +238,47 @@ int trpx_header_parse(const char* data, size_t len, trpx_header* h, size_t* payl
 size_t trpx_header_format_indexed(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, char* buf, size_t buf_cap);
 size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity);
 
+/* Group states (row f1, second half): even with the frame sizes a reader has to walk each frame's header chain before it can
+ * expand anything (Terse.hpp:360-372: a block's position is only known after the header of the block before it).  The chain
+ * state at every 256th block -- bit offset inside the frame and width of the block before it, packed as
+ * offset | width << 40 -- lets every 256-block group be walked on its own: trpx_group_count(n_values, 12) states per frame.
+ *   trpx_index_group_states          reads them off a decode index (device);
+ *   trpx_index_from_group_states     rebuilds the decode index from them (device, one lane per group) and checks every
+ *                                    group against its successor's state and the frame's size (TRPX_ERR_CORRUPT);
+ *   trpx_group_states_host           the states of a stack in host memory (what `terse -index` writes);
+ *   trpx_decode_host_grouped         trpx_decode_host with the states: no walk; falls back to trpx_decode_host when the
+ *                                    output type needs conversion or the states do not fit the stream;
+ *   trpx_header_format_grouped       the header text with frame_sizes="..." and group_bit_offsets="o:w o:w ..." (~0.8 % of a
+ *                                    synth-v1 stack's size; ignored by the reference reader like any unknown attribute,
+ *                                    XML_element.hpp:296-307), trpx_header_group_states reads the attribute back. */
+size_t trpx_group_count(size_t n_values, unsigned block);
+int trpx_index_group_states(const void* index, size_t n_values, size_t n_frames, unsigned block, uint64_t* group_states, void* stream);
+int trpx_index_from_group_states(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                                 const uint64_t* group_states, size_t n_values, size_t n_frames, unsigned block, void* index,
+                                 uint32_t* status, void* stream);
+int trpx_group_states_host(const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets, size_t n_values,
+                           size_t n_frames, unsigned block, unsigned max_bits, uint64_t* group_states, int device);
+int trpx_decode_host_grouped(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                             const uint64_t* group_states, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
+                             int device);
+size_t trpx_header_format_grouped(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, const uint64_t* group_states,
+                                  size_t n_states, char* buf, size_t buf_cap);
+size_t trpx_header_group_states(const char* data, size_t len, uint64_t* group_states, size_t capacity);
+
 /* ---- host callers that work frame by frame ---------------------------------------------
  * src/prolix.cpp:69-92 expands a .trpx file with one `trpx_data.prolix(image, i)` per frame, src/terse.cpp:63-69 pushes
  * one image at a time.  The *_host entry points keep their device buffers per calling thread between calls (no
  * allocation per frame; trpx_host_release frees them).  For the expanding loop a stack object keeps the compressed stack
  * on the device: trpx_stack_open uploads it once (frame_offsets may be NULL: the frames are then located by the serial
- * walk, Terse.hpp:562-585, max_bits as in trpx_frame_offsets_host), trpx_stack_read(frame) expands a window of frames
+ * walk, Terse.hpp:562-585, max_bits as in trpx_frame_offsets_host; group_states, if the file carried them, make the
+ * expansion walk-free), trpx_stack_read(frame) expands a window of frames
  * starting at `frame` in ONE device call on a miss (<= 64 MB of pixels) and afterwards only copies the frame asked for
  * -- any output type of trpx_decode_host.  Not thread safe per object (the reference's prolix is not const either,
  * Terse.hpp:387-388). */
 typedef struct trpx_stack trpx_stack;
 int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
-                    size_t n_values, size_t n_frames, unsigned block, unsigned max_bits, int device);
+                    const uint64_t* group_states /* may be NULL */, size_t n_values, size_t n_frames, unsigned block,
+                    unsigned max_bits, int device);
 int trpx_stack_read(trpx_stack* stack, size_t frame, int out_dtype, void* pixels_out);
 void trpx_stack_close(trpx_stack* stack);
 void trpx_host_release(void);

@@ -125,6 +125,21 @@ def widths(px: np.ndarray, block: int = 12) -> np.ndarray:
     return w
 
 
+def group_states(px: np.ndarray, group_blocks: int = 256, block: int = 12) -> np.ndarray:
+    """Chain state of ONE frame at every `group_blocks`-th block, from the widths alone: bit offset inside the frame |
+    width of the block before << 40.  Header lengths as Terse.hpp:520-541 writes them (1 bit when the width repeats, else
+    4 / 6 / 12 bits), payload = block values x width (Terse.hpp:543)."""
+    px = np.ascontiguousarray(px).reshape(-1)
+    w = widths(px, block).astype(np.int64)
+    prev = np.concatenate([[0], w[:-1]])
+    hl = np.where(w == prev, 1, np.where(w < 7, 4, np.where(w < 10, 6, 12)))
+    nv = np.full(w.size, block, np.int64)
+    nv[-1] = px.size - (w.size - 1) * block
+    pos = np.concatenate([[0], np.cumsum(hl + nv * w)])
+    k = np.arange(0, w.size, group_blocks)
+    return (pos[k] | (prev[k] << 40)).astype(np.uint64)
+
+
 def encode(px: np.ndarray, block: int = 12):
     """Encode ONE frame. Returns (stream bytes as np.uint8 array, prolix_bits)."""
     px = np.ascontiguousarray(px).reshape(-1)

@@ -24,7 +24,10 @@ const char* trpx_last_error_string(void) { return "host sanitizer build: no devi
 int trpx_encode_host(int, const void*, size_t, size_t, unsigned, uint8_t*, size_t, size_t*, uint64_t*, uint32_t*, int) { return no_device(); }
 int trpx_decode_host(int, int, const uint8_t*, size_t, const uint64_t*, size_t, size_t, unsigned, void*, int) { return no_device(); }
 int trpx_frame_offsets_host(const uint8_t*, size_t, size_t, size_t, unsigned, unsigned, uint64_t*, int) { return no_device(); }
-int trpx_stack_open(trpx_stack**, int, const uint8_t*, size_t, const uint64_t*, size_t, size_t, unsigned, unsigned, int) { return no_device(); }
+int trpx_stack_open(trpx_stack**, int, const uint8_t*, size_t, const uint64_t*, const uint64_t*, size_t, size_t, unsigned, unsigned, int) { return no_device(); }
+int trpx_group_states_host(const uint8_t*, size_t, const uint64_t*, size_t, size_t, unsigned, unsigned, uint64_t*, int) { return no_device(); }
+int trpx_decode_host_grouped(int, int, const uint8_t*, size_t, const uint64_t*, const uint64_t*, size_t, size_t, unsigned, void*, int) { return no_device(); }
+size_t trpx_group_count(size_t n, unsigned block) { return block == 12 ? ((n + 11) / 12 + 255) / 256 : 0; }
 int trpx_stack_read(trpx_stack*, size_t, int, void*) { return no_device(); }
 void trpx_stack_close(trpx_stack*) {}
 size_t trpx_worst_case_bytes(int, size_t n, unsigned) { return 8 * n + 64; }
@@ -60,6 +63,22 @@ static void headers() {
     EXPECT(trpx_header_frame_sizes(ibuf, ilen, back, 3) == 3 && back[2] == 101750);
     uint64_t one[1];
     (void)trpx_header_frame_sizes(ibuf, ilen, one, 1);                      // capacity smaller than the attribute
+    {   // group states: "offset:width" tokens, round trip and hostile values
+        const uint64_t gs[4] = {0, 12345ull | (3ull << 40), (1ull << 40) - 1, 77ull | (64ull << 40)};
+        char gbuf[1024];
+        const size_t glen = trpx_header_format_grouped(&h, sizes, 3, gs, 4, gbuf, sizeof gbuf);
+        EXPECT(glen > ilen);
+        uint64_t gb[4] = {1, 1, 1, 1};
+        EXPECT(trpx_header_group_states(gbuf, glen, gb, 4) == 4 && gb[1] == gs[1] && gb[2] == gs[2] && gb[3] == gs[3]);
+        EXPECT(trpx_header_frame_sizes(gbuf, glen, back, 3) == 3);
+        trpx_header t{};
+        size_t o = 0;
+        EXPECT(trpx_header_parse(gbuf, glen, &t, &o) == TRPX_OK && o == glen);
+        for (size_t n = 0; n < glen; ++n) { std::vector<char> cut(gbuf, gbuf + n); uint64_t x[2]; (void)trpx_header_group_states(cut.data(), cut.size(), x, 2); }
+        const char* evil[] = {"<Terse group_bit_offsets=\"1:2 3: 4:5\"/>", "<Terse group_bit_offsets=\"99999999999999999999:1\"/>",
+                              "<Terse group_bit_offsets=\"1:999 2:3\"/>", "<Terse group_bit_offsets=\":::: 1:1\"/>", "<Terse group_bit_offsets=\"5:6"};
+        for (const char* e : evil) { std::vector<char> m(e, e + std::strlen(e)); uint64_t x[3]; EXPECT(trpx_header_group_states(m.data(), m.size(), x, 3) <= 3); }
+    }
     // every prefix: parse must fail cleanly (never read past `len`; the buffers are exact-size heap blocks for ASan)
     for (size_t n = 0; n < ilen; ++n) {
         std::vector<char> cut(ibuf, ibuf + n);

@@ -116,8 +116,8 @@ def test_prolix_cli_expands_the_reference_trpx(name, tmp_path):
 
 
 def _indexed_trpx(name):
-    """The reference `terse`'s file of a fixture with the frame_sizes attribute added (row f1), built on the CPU:
-    frame sizes from the oracle, header text from the library's host-only formatter."""
+    """The reference `terse`'s file of a fixture with the frame_sizes and group_bit_offsets attributes added (row f1),
+    built on the CPU: frame sizes and group states from the oracle, header text from the library's host-only formatter."""
     import ctypes as C
     import sys
     sys.path.insert(0, ROOT)
@@ -132,32 +132,75 @@ def _indexed_trpx(name):
     off = C.c_size_t(0)
     assert _lib.lib().trpx_header_parse(blob, len(blob), C.byref(h), C.byref(off)) == _lib.OK
     assert blob[off.value:] == stream.tobytes()              # the oracle agrees with the reference tool's payload
-    buf = C.create_string_buffer(4096)
+    buf = C.create_string_buffer(1 << 16)
     s64 = np.asarray(sizes, np.uint64)
-    n = _lib.lib().trpx_header_format_indexed(C.byref(h), s64.ctypes.data, s64.size, buf, 4096)
-    assert n > 0 and b' frame_sizes="' in buf.raw[:n]
+    gs = np.concatenate([O.group_states(f) for f in px])
+    assert gs.size == px.shape[0] * _lib.lib().trpx_group_count(px.shape[1], 12)
+    n = _lib.lib().trpx_header_format_grouped(C.byref(h), s64.ctypes.data, s64.size, gs.ctypes.data, gs.size, buf, 1 << 16)
+    assert n > 0 and b' frame_sizes="' in buf.raw[:n] and b' group_bit_offsets="0:0' in buf.raw[:n]
     back = np.zeros(s64.size, np.uint64)
     assert _lib.lib().trpx_header_frame_sizes(buf.raw[:n], n, back.ctypes.data, back.size) == s64.size and (back == s64).all()
     assert _lib.lib().trpx_header_frame_sizes(blob, len(blob), back.ctypes.data, back.size) == 0   # plain header: none
+    gback = np.zeros(gs.size, np.uint64)
+    assert _lib.lib().trpx_header_group_states(buf.raw[:n], n, gback.ctypes.data, gback.size) == gs.size and (gback == gs).all()
+    assert _lib.lib().trpx_header_group_states(blob, len(blob), gback.ctypes.data, gback.size) == 0
+    h2, off2 = _lib.trpx_header(), C.c_size_t(0)
+    assert _lib.lib().trpx_header_parse(buf.raw[:n], n, C.byref(h2), C.byref(off2)) == _lib.OK and off2.value == n
     return buf.raw[:n] + stream.tobytes()
 
 
 @pytest.mark.parametrize("name", ["u8_stack2_16x12", "u16_bigendian_24x24", "i16_single_17x9"])
 def test_reference_prolix_ignores_the_frame_index_attribute(name, tmp_path):
     """CPU, only where the reference tools can be built (/root/reference): a .trpx file with the extra frame_sizes
-    attribute expands with the REFERENCE `prolix` to the same TIFF as the plain file (stacks of <= 2 frames: the
+    and group_bit_offsets attributes expands with the REFERENCE `prolix` to the same TIFF as the plain file (stacks of <= 2 frames: the
     reference mislocates later frames either way, D1/D2)."""
     indexed = _indexed_trpx(name)
-    ref = os.path.join(ROOT, "oracle", "_ref", "prolix_cli")
-    if not os.path.exists(ref):
-        if not os.path.isdir("/root/reference"):
-            pytest.skip("reference sources not available here")
-        subprocess.check_call(["g++", "-std=c++20", "-O2", "-w", "-I/root/reference/include", "/root/reference/src/prolix.cpp",
-                               "-o", ref])
+    ref = _reference_prolix()
     work = tmp_path / (name + ".trpx")
     work.write_bytes(indexed)
     subprocess.check_call([ref, str(work)], stdout=subprocess.DEVNULL)
     assert (tmp_path / (name + ".tif")).read_bytes() == open(os.path.join(CLI, INDEX[name]["expect_tif"]), "rb").read()
+
+
+def _reference_prolix():
+    ref = os.path.join(ROOT, "oracle", "_ref", "prolix_cli")
+    if not os.path.exists(ref):
+        if not os.path.isdir("/root/reference"):
+            pytest.skip("reference sources not available here")
+        os.makedirs(os.path.dirname(ref), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++20", "-O2", "-w", "-I/root/reference/include", "/root/reference/src/prolix.cpp",
+                               "-o", ref])
+    return ref
+
+
+def test_reference_prolix_reads_a_file_with_many_group_states(tmp_path):
+    """CPU, where the reference tool can be built: two 200x160 u16 frames (2667 blocks = 11 groups each, a 22-token
+    group_bit_offsets attribute of several hundred characters) written with both index attributes expand with the
+    REFERENCE `prolix` to the original pixels -- the attributes are skipped like any unknown one (XML_element.hpp:296-307)."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from trpx_amd import _lib
+    ref = _reference_prolix()
+    rng = np.random.RandomState(5)
+    px = (rng.poisson(3.0, size=(2, 160 * 200)) * (rng.rand(2, 160 * 200) < 0.7)).astype(np.uint16)
+    px[:, ::97] = 40000
+    stream, sizes, pb = O.encode_stack(px)
+    h = _lib.trpx_header()
+    h.prolix_bits, h.is_signed, h.block, h.memory_size, h.number_of_values = pb, 0, 12, stream.size, px.shape[1]
+    h.number_of_frames, h.n_dims = 2, 2
+    h.dims[0], h.dims[1] = 200, 160
+    gs = np.concatenate([O.group_states(f) for f in px])
+    assert gs.size == 22 and gs[1] > 0 and gs[11] == 0
+    s64 = np.asarray(sizes, np.uint64)
+    buf = C.create_string_buffer(1 << 14)
+    n = _lib.lib().trpx_header_format_grouped(C.byref(h), s64.ctypes.data, 2, gs.ctypes.data, gs.size, buf, 1 << 14)
+    assert n > 300
+    work = tmp_path / "many.trpx"
+    work.write_bytes(buf.raw[:n] + stream.tobytes())
+    subprocess.check_call([ref, str(work)], stdout=subprocess.DEVNULL)
+    assert (_parse_tiff(str(tmp_path / "many.tif")).reshape(2, -1) == px).all()
 
 
 @pytest.mark.gpu

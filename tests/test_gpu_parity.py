@@ -746,7 +746,7 @@ def test_device_resident_stack_read_frame_by_frame(gpu, oracle):
     for with_offsets in (True, False):
         h = C.c_void_p()
         _lib.check(L.trpx_stack_open(C.byref(h), 0, stream.ctypes.data, stream.size, offs.ctypes.data if with_offsets else None,
-                                     n, frames, 12, 16, -1))
+                                     None, n, frames, 12, 16, -1))
         try:
             out = np.zeros(n, np.uint16)
             for f in list(range(frames)) + [5, 39, 0, 33, 31, 32]:
@@ -766,7 +766,7 @@ def test_device_resident_stack_read_frame_by_frame(gpu, oracle):
     bad = stream.copy()
     bad[int(offs[3]) + 2: int(offs[3]) + 9] ^= 0xFF
     h = C.c_void_p()
-    _lib.check(L.trpx_stack_open(C.byref(h), 0, bad.ctypes.data, bad.size, offs.ctypes.data, n, frames, 12, 16, -1))
+    _lib.check(L.trpx_stack_open(C.byref(h), 0, bad.ctypes.data, bad.size, offs.ctypes.data, None, n, frames, 12, 16, -1))
     try:
         out = np.zeros(n, np.uint16)
         rc = L.trpx_stack_read(h, 0, _lib.U16, out.ctypes.data)
@@ -774,6 +774,102 @@ def test_device_resident_stack_read_frame_by_frame(gpu, oracle):
         assert rc in (_lib.OK, _lib.ERR_CORRUPT)
     finally:
         L.trpx_stack_close(h)
+
+
+@pytest.mark.parametrize("dtype,n,frames", [(np.uint16, 512 * 512, 5), (np.int32, 700 * 700, 3), (np.uint8, 12 * 256 * 3 + 8, 4),
+                                            (np.int16, 12 * 256, 3), (np.uint16, 40, 2)])
+def test_group_states_for_walk_free_decode_of_files(gpu, oracle, dtype, n, frames, tmp_path):
+    """Row f1 (second half): the chain state at every 256th block.  States read off the encoder's index == states computed
+    from oracle.widths(); the index rebuilt from the states == the encoder's index; host decode with the states is
+    pixel-identical; states that do not fit the stream are detected (device route) or ignored (host route, which falls
+    back to the walk); a stack object opened with states serves frames; both Terse classes carry them through a file."""
+    import io
+    import torch
+    from trpx_amd import codec, _lib, Terse
+    L = _lib.lib()
+    dt = np.dtype(dtype)
+    rng = np.random.RandomState(n % 1000 + frames)
+    hi = rng.randint(0, 8 * dt.itemsize - 2, size=(frames, (n + 11) // 12))
+    px = (rng.rand(frames, ((n + 11) // 12) * 12) * 2.0 ** np.repeat(hi, 12, axis=1)).astype(np.int64)[:, :n]
+    if dt.kind == "i":
+        px = px * rng.choice([-1, 1], size=px.shape)
+    px = px.astype(dt)
+    want_states = np.concatenate([oracle.group_states(f) for f in px])
+    ng = L.trpx_group_count(n, 12)
+    assert ng == ((n + 11) // 12 + 255) // 256 and want_states.size == frames * ng and L.trpx_group_count(n, 7) == 0
+    dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(codec.torch_dtype(dt))
+    enc = codec.encode(dpx, index=True)
+    torch.cuda.synchronize()
+    enc.check()
+    # index -> states
+    d_states = torch.zeros(frames * ng, dtype=torch.int64, device=gpu)
+    _lib.check(L.trpx_index_group_states(enc.index.data_ptr(), n, frames, 12, d_states.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (d_states.cpu().numpy().view(np.uint64) == want_states).all()
+    # states -> index
+    rebuilt = torch.full_like(enc.index, 0x5A)
+    st = torch.zeros(8, dtype=torch.int32, device=gpu)
+    stack = enc.stack()
+    _lib.check(L.trpx_index_from_group_states(codec.dtype_code(dt), stack.data_ptr(), stack.numel(), enc.frame_offsets.data_ptr(),
+                                              d_states.data_ptr(), n, frames, 12, rebuilt.data_ptr(), st.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0
+    nb = (n + 11) // 12
+    w_off = (8 * frames * ng + 15) // 16 * 16
+    assert torch.equal(enc.index[: 8 * frames * ng], rebuilt[: 8 * frames * ng])
+    assert torch.equal(enc.index[w_off: w_off + frames * nb], rebuilt[w_off: w_off + frames * nb])
+    back, st2 = codec.decode(stack, enc.frame_offsets, n, frames, dt, index=rebuilt)
+    torch.cuda.synchronize()
+    assert int(st2[0].item()) == 0 and (back.cpu().numpy().view(dt).reshape(frames, n) == px).all()
+    # wrong states are detected on the device: offset off by one bit / previous width changed / first state not zero
+    for which, delta in ((frames * ng - 1, 1), (ng - 1, 1 << 40), (0, 1)):
+        bad = d_states.clone()
+        bad[which] += delta
+        _lib.check(L.trpx_index_from_group_states(codec.dtype_code(dt), stack.data_ptr(), stack.numel(), enc.frame_offsets.data_ptr(),
+                                                  bad.data_ptr(), n, frames, 12, rebuilt.data_ptr(), st.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert int(st[0].item()) == _lib.ERR_CORRUPT, (which, delta)
+    # host route: states of a host stack, decode with them, decode with wrong ones (falls back to the walking decoder)
+    h_stack = stack.cpu().numpy()
+    offs = enc.frame_offsets.cpu().numpy().astype(np.uint64)
+    got_states = np.zeros(frames * ng, np.uint64)
+    _lib.check(L.trpx_group_states_host(h_stack.ctypes.data, h_stack.size, offs.ctypes.data, n, frames, 12, 8 * dt.itemsize,
+                                        got_states.ctypes.data, -1))
+    assert (got_states == want_states).all()
+    for states in (want_states, want_states + np.uint64(3), None):
+        out = np.zeros((frames, n), dt)
+        _lib.check(L.trpx_decode_host_grouped(int(dt.kind == "i"), codec.dtype_code(dt), h_stack.ctypes.data, h_stack.size, offs.ctypes.data,
+                                              states.ctypes.data if states is not None else None, n, frames, 12, out.ctypes.data, -1))
+        assert (out == px).all()
+    wide = np.zeros((frames, n), np.float64)                                   # converting output: general route
+    _lib.check(L.trpx_decode_host_grouped(int(dt.kind == "i"), _lib.F64, h_stack.ctypes.data, h_stack.size, offs.ctypes.data,
+                                          want_states.ctypes.data, n, frames, 12, wide.ctypes.data, -1))
+    assert (wide == px.astype(np.float64)).all()
+    for states in (want_states, want_states ^ np.uint64(1)):                   # the stack object, right and wrong states
+        h = C.c_void_p()
+        _lib.check(L.trpx_stack_open(C.byref(h), int(dt.kind == "i"), h_stack.ctypes.data, h_stack.size, offs.ctypes.data,
+                                     states.ctypes.data, n, frames, 12, 0, -1))
+        try:
+            one = np.zeros(n, dt)
+            for f in (frames - 1, 0, 1):
+                _lib.check(L.trpx_stack_read(h, f, codec.dtype_code(dt), one.ctypes.data))
+                assert (one == px[f]).all()
+        finally:
+            L.trpx_stack_close(h)
+    # the classes: write(frame_index=True) computes and writes the states, read() brings them back, prolix uses them
+    t = Terse()
+    for f in px:
+        t.push_back(f)
+    assert not t.has_group_index()
+    out = io.BytesIO()
+    t.write(out, frame_index=True)
+    assert t.has_group_index() and b' group_bit_offsets="0:0' in out.getvalue()[:out.getvalue().index(b"/>")]
+    t2 = Terse.read(io.BytesIO(out.getvalue()))
+    assert t2.has_group_index() and (t2._group_states == want_states).all()
+    assert (t2.prolix_stack(dt) == px).all() and (t2.prolix(np.zeros(n, dt), 1) == px[1]).all()
+    t2.push_back(px[0])
+    assert not t2.has_group_index() and (t2.prolix(np.zeros(n, dt), frames) == px[0]).all()
+    L.trpx_host_release()
 
 
 def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):

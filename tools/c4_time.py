@@ -23,3 +23,24 @@ pix = frames * n * 4
 print("size frame0", int(enc.frame_offsets[1]), "total", total, "prolix_bits", enc.prolix_bits())
 print("encode stages ms", e, "-> fps", frames / e.sum() * 1e3, "pixel GB/s", pix / e.sum() / 1e6, "algorithmic GB/s", (pix + total) / e.sum() / 1e6)
 print("decode stages ms", d, "-> fps", frames / d.sum() * 1e3, "pixel GB/s", pix / d.sum() / 1e6)
+# row f1 for files: chain states at every 256th block -> index -> walk-free decode (what a reader of a `terse -index` file does)
+enc_i = codec.encode(px, workspace=ws, index=True); torch.cuda.synchronize()
+ng = L.trpx_group_count(n, 12)
+states = torch.zeros(frames * ng, dtype=torch.int64, device="cuda")
+_lib.check(L.trpx_index_group_states(enc_i.index.data_ptr(), n, frames, 12, states.data_ptr(), None))
+idx = torch.zeros_like(enc_i.index)
+st8 = torch.zeros(8, dtype=torch.int32, device="cuda")
+stack = enc_i.stack()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+tt = []
+for _ in range(5):
+    ev[0].record()
+    _lib.check(L.trpx_index_from_group_states(codec.dtype_code(np.int32), stack.data_ptr(), stack.numel(), enc_i.frame_offsets.data_ptr(),
+                                              states.data_ptr(), n, frames, 12, idx.data_ptr(), st8.data_ptr(), None))
+    ev[1].record()
+    back2, st2 = codec.decode(stack, enc_i.frame_offsets, n, frames, np.int32, index=idx, out=back, workspace=ws)
+    ev[2].record(); torch.cuda.synchronize()
+    tt.append((ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])))
+assert int(st8[0]) == 0 and int(st2[0]) == 0 and torch.equal(back2, px)
+tt = np.median(np.array(tt), 0)
+print("grouped decode: states->index ms", tt[0], "indexed unpack ms", tt[1], "states bytes", 8 * frames * ng, "of", total)

@@ -1,0 +1,38 @@
+"""Randomised differential run on the GPU box: random pixel types, frame sizes, frame counts and width patterns, encoded by
+the GPU (compared with the oracle's bytes) and decoded along the path selected by $TRPX_DECODE_PATH (compared with the
+pixels).  `python tools/fuzz_paths.py [cases] [seed]`; run it once per decode path."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from trpx_amd import codec
+from oracle import oracle as O
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+DT = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32]
+TDT = {np.uint8: torch.uint8, np.int8: torch.int8, np.uint16: torch.uint16, np.int16: torch.int16, np.uint32: torch.uint32, np.int32: torch.int32}
+t0 = time.time()
+for c in range(cases):
+    dt = np.dtype(DT[rng.randint(6)])
+    top = 8 * dt.itemsize - (2 if dt.kind == "i" else (1 if dt.itemsize == 4 else 0))      # inside the reference's validity domain (D3)
+    n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3)]))
+    n -= n % 4
+    frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else int(rng.choice([1, 3, 130]))
+    nblk = (n + 11) // 12
+    kind = rng.randint(5)
+    if kind == 0:   hi = np.full((frames, nblk), rng.randint(0, top + 1))                    # one width
+    elif kind == 1: hi = rng.randint(0, top + 1, size=(frames, nblk))                        # every block its own width
+    elif kind == 2: hi = np.where(rng.rand(frames, nblk) < 0.02, rng.randint(0, top + 1, size=(frames, nblk)), 3 if top >= 3 else 1)   # runs + outliers
+    elif kind == 3: hi = np.where(rng.rand(frames, nblk) < 0.5, 2, 3 if top >= 3 else 1)    # flips every other block
+    else:           hi = np.repeat(rng.randint(0, top + 1, size=(frames, (nblk + 299) // 300)), 300, axis=1)[:, :nblk]   # long runs of changing widths
+    mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+    if rng.rand() < 0.3: mag[:, : n // 2] = 0                                                 # empty half frames
+    if dt.kind == "i": mag = mag * rng.choice([-1, 1], size=mag.shape)
+    px = mag.astype(dt)
+    want, sizes, pb = O.encode_stack(px)
+    dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).cuda().view(TDT[dt.type])
+    enc = codec.encode(dpx); torch.cuda.synchronize(); enc.check()
+    assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb, ("encode", c, dt, n, frames, kind)
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt); torch.cuda.synchronize()
+    assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), ("decode", c, dt, n, frames, kind, int(st[0]))
+    if c % 20 == 0: print(f"case {c} ok ({time.time() - t0:.0f} s)", flush=True)
+print(f"OK {cases} cases, path {os.environ.get('TRPX_DECODE_PATH', 'default')}")

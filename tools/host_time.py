@@ -20,7 +20,7 @@ for rep in range(4):
 
 # per-frame expansion (src/prolix.cpp:69-92's loop): the stack stays on the device, a window of frames per device call
 h = C.c_void_p()
-_lib.check(L.trpx_stack_open(C.byref(h), 0, out.ctypes.data, total.value, offs.ctypes.data, n, frames, 12, 0, -1))
+_lib.check(L.trpx_stack_open(C.byref(h), 0, out.ctypes.data, total.value, offs.ctypes.data, None, n, frames, 12, 0, -1))
 one = np.empty(n, np.uint16)
 for rep in range(3):
     t0 = time.perf_counter()

@@ -59,7 +59,14 @@ SYMBOLS = {
     "trpx_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
     "trpx_comm_destroy": (_I, [_P]),
     "trpx_shard_last_error": (C.c_char_p, []),
-    "trpx_stack_open": (_I, [C.POINTER(_P), _I, _P, _SZ, _P, _SZ, _SZ, _U, _U, _I]),
+    "trpx_stack_open": (_I, [C.POINTER(_P), _I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _U, _I]),
+    "trpx_group_count": (_SZ, [_SZ, _U]),
+    "trpx_index_group_states": (_I, [_P, _SZ, _SZ, _U, _P, _P]),
+    "trpx_index_from_group_states": (_I, [_I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _P, _P, _P]),
+    "trpx_group_states_host": (_I, [_P, _SZ, _P, _SZ, _SZ, _U, _U, _P, _I]),
+    "trpx_decode_host_grouped": (_I, [_I, _I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _P, _I]),
+    "trpx_header_format_grouped": (_SZ, [C.POINTER(trpx_header), C.c_void_p, _SZ, C.c_void_p, _SZ, C.c_char_p, _SZ]),
+    "trpx_header_group_states": (_SZ, [C.c_char_p, _SZ, C.c_void_p, _SZ]),
     "trpx_stack_read": (_I, [_P, _SZ, _I, _P]),
     "trpx_stack_close": (None, [_P]),
     "trpx_host_release": (None, []),

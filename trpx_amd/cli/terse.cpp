@@ -67,8 +67,8 @@ int main(int argc, char const* argv[]) {
                      "  -help      print help\n"
                      "  -verbose   print compressed filenames, compute times and compression rate\n"
                      "  -delete    delete each TIFF file after it has been compressed (the reference tool always does)\n"
-                     "  -index     add the frame_sizes attribute to the header (ignored by the reference reader; lets prolix locate\n"
-                     "             the frames of a stack without walking them)\n";
+                     "  -index     add the frame_sizes and group_bit_offsets attributes to the header (ignored by the reference reader;\n"
+                     "             they let prolix locate the frames of a stack and expand them without walking their headers)\n";
         return 0;
     }
     std::chrono::duration<double> user_time(0), io_time(0);

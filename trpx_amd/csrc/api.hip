@@ -343,6 +343,53 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     return TRPX_OK;
 }
 
+size_t trpx_group_count(size_t n_values, unsigned block) {
+    trpx::FrameGeom g;
+    if (block != (unsigned)trpx::kBlock || !geom_of(n_values, block, &g)) return 0;
+    return g.n_tiles;
+}
+
+int trpx_index_group_states(const void* index, size_t n_values, size_t n_frames, unsigned block, uint64_t* states, void* stream) {
+    trpx::FrameGeom g;
+    if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_index_group_states: the decode index needs block=12");
+    if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames)) return fail(TRPX_ERR_INVALID_ARG, "trpx_index_group_states: bad sizes");
+    if (!index || !states || (uintptr_t)index % 16 || (uintptr_t)states % 8) return fail(TRPX_ERR_INVALID_ARG, "trpx_index_group_states: null / misaligned pointer");
+    const IdxLayout il = idx_layout(g, n_frames);
+    trpx::DecodeArgs a{};
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.tile_off = reinterpret_cast<uint64_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.group_off);
+    a.widths = reinterpret_cast<uint8_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.widths);
+    HIP_TRY(trpx::launch_index_group_states(a, states, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+int trpx_index_from_group_states(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                                 const uint64_t* states, size_t n_values, size_t n_frames, unsigned block, void* index,
+                                 uint32_t* status, void* stream) {
+    trpx::FrameGeom g;
+    if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_index_from_group_states: the decode index needs block=12");
+    if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || !terse_bytes)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_index_from_group_states: bad dtype/sizes");
+    if (!terse || !frame_offsets || !states || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_index_from_group_states: null pointer");
+    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || ((uintptr_t)frame_offsets | (uintptr_t)states | (uintptr_t)status) % 8)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_index_from_group_states: misaligned pointer");
+    if (8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) >= (1ull << 40))
+        return fail(TRPX_ERR_UNSUPPORTED, "trpx_index_from_group_states: frames of >= 2^40 bits");
+    const IdxLayout il = idx_layout(g, n_frames);
+    trpx::DecodeArgs a{};
+    a.terse = terse;
+    a.terse_bytes = terse_bytes;
+    a.frame_offsets = frame_offsets;
+    a.geom = g;
+    a.n_frames = (uint32_t)n_frames;
+    a.status = status;
+    a.tile_off = reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off);
+    a.widths = reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths);
+    HIP_TRY(trpx::launch_walk_groups(a, (uint32_t)(8 * trpx_dtype_size(dtype)), states, true, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
 int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes,
                         const uint64_t* frame_offsets, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
                         uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
@@ -586,6 +633,83 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
 }
 
 
+int trpx_group_states_host(const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets, size_t n_values,
+                           size_t n_frames, unsigned block, unsigned max_bits, uint64_t* group_states, int device) {
+    if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_group_states_host: no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    trpx::FrameGeom g;
+    if (!terse || !terse_bytes || !frame_offsets || !group_states || max_bits == 0 || max_bits > 32)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_group_states_host: bad argument");
+    if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_group_states_host: block=%u", block);
+    if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || n_frames > terse_bytes)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_group_states_host: bad sizes");
+    const int dtype = max_bits <= 8 ? TRPX_U8 : max_bits <= 16 ? TRPX_U16 : TRPX_U32;
+    const size_t ib = trpx_index_bytes(dtype, n_values, n_frames, block), ng = n_frames * (size_t)g.n_tiles;
+    struct { void* p = nullptr; } d_in, d_off, d_st, d_idx;
+    Arena& A = arena();
+    HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
+    HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1) + 8 * ng, &d_off.p));
+    HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
+    HIP_TRY(A.get(Arena::kWorkspace, ib, &d_idx.p));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));
+    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
+    uint64_t* d_states = static_cast<uint64_t*>(d_off.p) + (n_frames + 1);
+    int rc = trpx_build_index(dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, static_cast<const uint64_t*>(d_off.p), n_values,
+                              n_frames, block, d_idx.p, static_cast<uint32_t*>(d_st.p), nullptr);
+    if (rc) return rc;
+    rc = trpx_index_group_states(d_idx.p, n_values, n_frames, block, d_states, nullptr);
+    if (rc) return rc;
+    uint32_t st[TRPX_STATUS_WORDS];
+    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0]) return fail((int)st[0], "trpx_group_states_host: corrupt or truncated stack (device status %u)", st[0]);
+    HIP_TRY(hipMemcpy(group_states, d_states, 8 * ng, hipMemcpyDeviceToHost));
+    return TRPX_OK;
+}
+
+int trpx_decode_host_grouped(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
+                             const uint64_t* group_states, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
+                             int device) {
+    // the tuned, walk-free route needs a same-signedness integer type and vector-aligned frames; everything else (and a
+    // state table that does not fit the stream) goes the general way
+    trpx::FrameGeom g;
+    const bool tuned = group_states && frame_offsets && out_dtype <= TRPX_I32 && trpx_dtype_size(out_dtype) &&
+                       (stream_signed != 0) == (trpx_dtype_is_signed(out_dtype) != 0) && block == (unsigned)trpx::kBlock &&
+                       n_values % 4 == 0 && geom_of(n_values, block, &g) && sizes_ok(g, n_frames);
+    if (!tuned) return trpx_decode_host(stream_signed, out_dtype, terse, terse_bytes, frame_offsets, n_values, n_frames, block, pixels_out, device);
+    if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_decode_host_grouped: no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    if (!terse || !terse_bytes || !pixels_out) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_host_grouped: bad argument");
+    const size_t es = trpx_dtype_size(out_dtype), out_bytes = n_values * n_frames * es, ng = n_frames * (size_t)g.n_tiles;
+    const size_t ib = trpx_index_bytes(out_dtype, n_values, n_frames, block);
+    struct { void* p = nullptr; } d_in, d_out, d_off, d_st, d_idx;
+    Arena& A = arena();
+    HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
+    HIP_TRY(A.get(Arena::kPixels, out_bytes, &d_out.p));
+    HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1) + 8 * ng, &d_off.p));
+    HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
+    HIP_TRY(A.get(Arena::kWorkspace, ib, &d_idx.p));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));
+    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
+    uint64_t* d_states = static_cast<uint64_t*>(d_off.p) + (n_frames + 1);
+    HIP_TRY(hipMemcpy(d_states, group_states, 8 * ng, hipMemcpyHostToDevice));
+    int rc = trpx_index_from_group_states(out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, static_cast<const uint64_t*>(d_off.p),
+                                          d_states, n_values, n_frames, block, d_idx.p, static_cast<uint32_t*>(d_st.p), nullptr);
+    if (rc) return rc;
+    uint32_t st[TRPX_STATUS_WORDS];
+    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0] == TRPX_ERR_CORRUPT)     // the states do not describe this stream (or the data are wider than the output type): general route
+        return trpx_decode_host(stream_signed, out_dtype, terse, terse_bytes, frame_offsets, n_values, n_frames, block, pixels_out, device);
+    rc = trpx_decode_indexed(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, static_cast<const uint64_t*>(d_off.p),
+                             d_idx.p, n_values, n_frames, block, d_out.p, static_cast<uint32_t*>(d_st.p), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0]) return fail((int)st[0], "trpx_decode_host_grouped: corrupt or truncated stream (device status %u)", st[0]);
+    HIP_TRY(hipMemcpy(pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    return TRPX_OK;
+}
+
 // ---- a compressed stack kept on the device, read frame by frame (src/prolix.cpp:69-92's loop shape) --------------------
 struct trpx_stack {
     int device = 0;
@@ -597,6 +721,9 @@ struct trpx_stack {
     void* d_status = nullptr;
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
+    void* d_states = nullptr;      // u64[n_frames * groups]: chain state at every 256th block (may be absent)
+    void* d_index = nullptr;       // decode index of the window's frames, rebuilt from the states (walk-free expansion)
+    size_t groups = 0;
     void* d_window = nullptr;      // decoded frames [win_first, win_first + win_count) as win_dtype
     size_t window_cap = 0, win_first = 0, win_count = 0, window_frames = 0;
     int win_dtype = -1;
@@ -605,12 +732,12 @@ struct trpx_stack {
 
 static void stack_free(trpx_stack* s) {
     if (!s) return;
-    for (void* q : {s->d_terse, s->d_offs, s->d_status, s->d_ws, s->d_window}) if (q) (void)hipFree(q);
+    for (void* q : {s->d_terse, s->d_offs, s->d_status, s->d_ws, s->d_window, s->d_states, s->d_index}) if (q) (void)hipFree(q);
     delete s;
 }
 
 int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
-                    size_t n_values, size_t n_frames, unsigned block, unsigned max_bits, int device) {
+                    const uint64_t* group_states, size_t n_values, size_t n_frames, unsigned block, unsigned max_bits, int device) {
     if (!handle) return fail(TRPX_ERR_INVALID_ARG, "trpx_stack_open: null handle");
     *handle = nullptr;
     if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_stack_open: no HIP device");
@@ -644,6 +771,12 @@ int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse
     if ((e = hipMemset(s->d_terse, 0, trpx::align_up(terse_bytes, 4) + 8)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemcpy(s->d_terse, terse, terse_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(stack)");
     if ((e = hipMemcpy(s->d_offs, s->offs.data(), 8 * (n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(offsets)");
+    if (group_states && block == (unsigned)trpx::kBlock && n_values % 4 == 0) {   // row f1: the file carried its group states
+        s->groups = g.n_tiles;
+        if ((e = hipMalloc(&s->d_states, 8 * n_frames * s->groups)) != hipSuccess) return bail(e, "hipMalloc(states)");
+        if ((e = hipMemcpy(s->d_states, group_states, 8 * n_frames * s->groups, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(states)");
+        if ((e = hipMalloc(&s->d_index, trpx_index_bytes(TRPX_U8, n_values, s->window_frames, block))) != hipSuccess) return bail(e, "hipMalloc(index)");
+    }
     *handle = s;
     return TRPX_OK;
 }
@@ -672,7 +805,22 @@ int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out
         const size_t bytes = (size_t)rel[count];
         bool convert = !(out_dtype <= TRPX_I32 && (s->stream_signed != 0) == (trpx_dtype_is_signed(out_dtype) != 0));
         uint32_t st[TRPX_STATUS_WORDS];
-        for (;;) {                                                             // (same routing as trpx_decode_host)
+        bool done = false;
+        if (s->d_states && !convert) {                                         // walk-free: index from the file's group states
+            int rc = trpx_index_from_group_states(out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs),
+                                                  static_cast<const uint64_t*>(s->d_states) + frame * s->groups, s->n_values, count,
+                                                  s->block, s->d_index, static_cast<uint32_t*>(s->d_status), nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
+            if (st[0] == 0) {
+                rc = trpx_decode_indexed(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs), s->d_index,
+                                         s->n_values, count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), nullptr);
+                if (rc) return rc;
+                HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
+                done = st[0] == 0;
+            }                                                                  // (states that do not fit the stream: the general route decides)
+        }
+        for (; !done;) {                                                       // (same routing as trpx_decode_host)
             const int rc = convert ? trpx_decode_convert(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs),
                                                          s->n_values, count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status),
                                                          s->d_ws, s->ws_bytes, nullptr)

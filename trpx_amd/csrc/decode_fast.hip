@@ -211,6 +211,85 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 6) void k_unpack_til
                    widths, tile_off, pixels_out, status, s_image, s_wtot, s_stage);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Group states (row f1 for files): the chain state (bit offset, width of the block before) at every 256th block is
+// all a decoder needs to walk a frame's groups independently.  k_index_group_states reads the states off a decode
+// index; k_walk_groups rebuilds the index from them -- one lane per group, 256 dependent steps, every group checked
+// against its successor's state (the last one against S_f = 1 + bits/8, Terse.hpp:547).
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kStateOffMask = (1ull << 40) - 1;
+
+__global__ __launch_bounds__(kThreads) void k_index_group_states(const uint8_t* __restrict__ widths, const uint64_t* __restrict__ tile_off,
+                                                                 FrameGeom g, uint64_t n_groups_total, uint64_t* __restrict__ states) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_groups_total) return;
+    const uint64_t frame = i / g.n_tiles, k = i % g.n_tiles;
+    const uint32_t w_prev = k ? widths[frame * g.n_blocks + k * kTileBlocks - 1] : 0u;
+    states[i] = (tile_off[i] & kStateOffMask) | ((uint64_t)w_prev << 40);
+}
+
+__global__ __launch_bounds__(kThreads) void k_walk_groups(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                          const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                          const uint64_t* __restrict__ states, uint64_t n_groups_total,
+                                                          uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                          uint32_t* __restrict__ status) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_groups_total) return;
+    const uint64_t frame = i / g.n_tiles;
+    const uint32_t k = (uint32_t)(i % g.n_tiles);
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    bool bad = !(fe > fo && fe <= terse_bytes);
+    const uint64_t limit = bad ? 0 : 8 * (fe - fo);
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(terse);
+    const uint64_t n_dw = (terse_bytes + 3) / 4;
+    const uint64_t st = states[i];
+    uint64_t pos = st & kStateOffMask;
+    uint32_t w = (uint32_t)(st >> 40);
+    if (k == 0 && st != 0) bad = true;                       // a frame starts at bit 0 with width 0 (Terse.hpp:359, :505)
+    if (pos > limit || w > max_w) bad = true;
+    const uint32_t b0 = k * kTileBlocks;
+    const uint32_t b1 = b0 + kTileBlocks < g.n_blocks ? b0 + kTileBlocks : g.n_blocks;
+    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);
+    if (!bad) tile_off[i] = pos;
+    for (uint32_t b = b0; b < b1 && !bad; ++b) {
+        const uint64_t abit = 8 * fo + pos, d = abit >> 5;
+        const uint64_t two = (uint64_t)(d < n_dw ? s32[d] : 0u) | ((uint64_t)(d + 1 < n_dw ? s32[d + 1] : 0u) << 32);
+        const uint32_t bits = (uint32_t)(two >> (abit & 31u));
+        uint32_t hl = 1;
+        if (!(bits & 1u)) {                                  // Terse.hpp:361-370
+            w = (bits >> 1) & 7u; hl = 4;
+            if (w == 7u) {
+                w += (bits >> 4) & 3u; hl = 6;
+                if (w == 10u) { w += (bits >> 6) & 63u; hl = 12; }
+            }
+        }
+        if (w > max_w) { bad = true; break; }
+        widths[frame * g.n_blocks + b] = (uint8_t)w;
+        pos += hl + (uint64_t)(b + 1 == g.n_blocks ? nb_last : (uint32_t)kBlock) * w;
+        if (pos > limit) bad = true;
+    }
+    if (!bad) {
+        if (b1 < g.n_blocks) bad = ((pos & kStateOffMask) | ((uint64_t)w << 40)) != states[i + 1];   // lands in the next group's state
+        else bad = 1 + pos / 8 != fe - fo;                                                           // S_f (Terse.hpp:547)
+    }
+    if (bad) atomicMax(&status[0], 5u);                      // TRPX_ERR_CORRUPT
+}
+
+hipError_t launch_index_group_states(const DecodeArgs& a, uint64_t* states, hipStream_t st) {
+    const uint64_t n = (uint64_t)a.n_frames * a.geom.n_tiles;
+    hipLaunchKernelGGL(k_index_group_states, dim3((uint32_t)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, a.widths, a.tile_off,
+                       a.geom, n, states);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, bool clear_status, hipStream_t st) {
+    if (clear_status) zero_status(a.status, st);
+    const uint64_t n = (uint64_t)a.n_frames * a.geom.n_tiles;
+    hipLaunchKernelGGL(k_walk_groups, dim3((uint32_t)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, a.terse,
+                       (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w, states, n, a.widths, a.tile_off, a.status);
+    return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hipStream_t st) {
     const FrameGeom g = a.geom;

@@ -56,6 +56,9 @@ hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
 // header walk only (fills a.widths / a.tile_off from the stream): builds the decode index of an existing stack
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
+// group states (chain state at every 256th block): read them off an index (a.widths / a.tile_off) / rebuild the index from them
+hipError_t launch_index_group_states(const DecodeArgs& a, uint64_t* states, hipStream_t st);
+hipError_t launch_walk_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, bool clear_status, hipStream_t st);
 // position-parallel header walk (decode_seg.hip): fills a.widths / a.tile_off like launch_walk_only; needs a.seg_ws
 size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st);

@@ -12,7 +12,8 @@
 
 #include "../../include/trpx_hip.h"
 
-static std::string header_string(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes);
+static std::string header_string(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, const uint64_t* group_states = nullptr,
+                                 size_t n_states = 0);
 
 extern "C" size_t trpx_header_format(const trpx_header* h, char* buf, size_t buf_cap) {
     if (!h || !buf) return 0;
@@ -31,7 +32,17 @@ extern "C" size_t trpx_header_format_indexed(const trpx_header* h, const uint64_
     return s.size();
 }
 
-static std::string header_string(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes) {
+extern "C" size_t trpx_header_format_grouped(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes,
+                                             const uint64_t* group_states, size_t n_states, char* buf, size_t buf_cap) {
+    if (!h || !buf || (!frame_sizes && n_sizes) || (!group_states && n_states)) return 0;
+    const std::string s = header_string(h, frame_sizes, n_sizes, group_states, n_states);
+    if (s.size() + 1 > buf_cap) return 0;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return s.size();
+}
+
+static std::string header_string(const trpx_header* h, const uint64_t* frame_sizes, size_t n_sizes, const uint64_t* group_states,
+                                 size_t n_states) {
     std::string s = "<Terse prolix_bits=\"" + std::to_string(h->prolix_bits) + "\"";
     s += " signed=\"" + std::to_string(h->is_signed ? 1 : 0) + "\"";
     s += " block=\"" + std::to_string(h->block) + "\"";
@@ -50,6 +61,14 @@ static std::string header_string(const trpx_header* h, const uint64_t* frame_siz
         for (size_t i = 0; i < n_sizes; ++i) {
             if (i) s += " ";
             s += std::to_string((unsigned long long)frame_sizes[i]);
+        }
+        s += "\"";
+    }
+    if (n_states) {                                           // row f1: chain state at every 256th block, "bit_offset:width_before"
+        s += " group_bit_offsets=\"";
+        for (size_t i = 0; i < n_states; ++i) {
+            if (i) s += " ";
+            s += std::to_string((unsigned long long)(group_states[i] & ((1ull << 40) - 1))) + ":" + std::to_string((unsigned)(group_states[i] >> 40));
         }
         s += "\"";
     }
@@ -114,14 +133,14 @@ extern "C" int trpx_header_parse(const char* data, size_t len, trpx_header* h, s
     return TRPX_OK;
 }
 
-// The optional frame_sizes attribute (trpx_header_format_indexed): same scan as trpx_header_parse.
-extern "C" size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity) {
-    if (!data) return 0;
+// Value of one attribute of the <Terse .../> element: same scan as trpx_header_parse.  Returns false if it is not there.
+static bool find_attribute(const char* data, size_t len, const char* wanted, std::string* value) {
+    if (!data) return false;
     static const char tag[] = "<Terse";
     const size_t tl = sizeof(tag) - 1;
     size_t p = 0;
     for (;; ++p) {
-        if (p + tl >= len) return 0;
+        if (p + tl >= len) return false;
         if (data[p] == '<' && memcmp(data + p, tag, tl) == 0 && (is_white(data[p + tl]) || data[p + tl] == '/' || data[p + tl] == '>')) break;
     }
     size_t q = p + tl;
@@ -131,29 +150,57 @@ extern "C" size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t
         while (q < len && data[q] != '=' && data[q] != '>' && !is_white(data[q])) ++q;
         const std::string name(data + ns, q - ns);
         while (q < len && is_white(data[q])) ++q;
-        if (q >= len || data[q] != '=') return 0;
+        if (q >= len || data[q] != '=') return false;
         ++q;
         while (q < len && is_white(data[q])) ++q;
-        if (q >= len) return 0;
+        if (q >= len) return false;
         const char quote = data[q++];
         const size_t vs = q;
         while (q < len && data[q] != quote) ++q;
-        if (q >= len) return 0;
-        if (name == "frame_sizes") {
-            const std::string val(data + vs, q - vs);
-            const char* t = val.c_str();
-            size_t n = 0;
-            for (;;) {
-                char* end = nullptr;
-                const unsigned long long v = strtoull(t, &end, 10);
-                if (end == t) break;
-                if (frame_sizes && n < capacity) frame_sizes[n] = v;
-                ++n;
-                t = end;
-            }
-            return n;
+        if (q >= len) return false;
+        if (name == wanted) {
+            value->assign(data + vs, q - vs);
+            return true;
         }
         ++q;
     }
-    return 0;
+    return false;
+}
+
+// The optional frame_sizes attribute (trpx_header_format_indexed).
+extern "C" size_t trpx_header_frame_sizes(const char* data, size_t len, uint64_t* frame_sizes, size_t capacity) {
+    std::string val;
+    if (!find_attribute(data, len, "frame_sizes", &val)) return 0;
+    const char* t = val.c_str();
+    size_t n = 0;
+    for (;;) {
+        char* end = nullptr;
+        const unsigned long long v = strtoull(t, &end, 10);
+        if (end == t) break;
+        if (frame_sizes && n < capacity) frame_sizes[n] = v;
+        ++n;
+        t = end;
+    }
+    return n;
+}
+
+// The optional group_bit_offsets attribute (trpx_header_format_grouped): tokens "offset:width"; a malformed token ends the list.
+extern "C" size_t trpx_header_group_states(const char* data, size_t len, uint64_t* group_states, size_t capacity) {
+    std::string val;
+    if (!find_attribute(data, len, "group_bit_offsets", &val)) return 0;
+    const char* t = val.c_str();
+    size_t n = 0;
+    for (;;) {
+        char* end = nullptr;
+        const unsigned long long off = strtoull(t, &end, 10);
+        if (end == t || *end != ':') break;
+        t = end + 1;
+        const unsigned long long w = strtoull(t, &end, 10);
+        if (end == t) break;
+        if (off >= (1ull << 40) || w > 64) break;
+        if (group_states && n < capacity) group_states[n] = off | ((uint64_t)w << 40);
+        ++n;
+        t = end;
+    }
+    return n;
 }

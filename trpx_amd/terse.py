@@ -49,6 +49,7 @@ class Terse:
         self._dim: list[int] = []
         self._data = bytearray()
         self._stack, self._stack_len = None, -1      # device-resident copy of the stack (prolix), see _drop_stack
+        self._group_states = None                    # chain state at every 256th block of every frame (row f1), or None
         self._frame_sizes: list[int] = []
         if data is not None:
             self.push_back(data)
@@ -96,6 +97,7 @@ class Terse:
             self._size = n
             self._signed = a.dtype.kind == "i"
         self._data += out[: total.value].tobytes()
+        self._group_states = None
         self._frame_sizes += [int(x) for x in np.diff(offs)]
         self._prolix_bits = max(self._prolix_bits, int(pb.value))   # Terse.hpp:516
 
@@ -118,11 +120,22 @@ class Terse:
             buf = np.frombuffer(self._data, np.uint8)
             offs = np.concatenate([[0], np.cumsum(self._frame_sizes)]).astype(np.uint64)
             h = C.c_void_p()
-            check(lib().trpx_stack_open(C.byref(h), int(self._signed), buf.ctypes.data, buf.size, offs.ctypes.data, self._size,
+            gs = self._states()
+            check(lib().trpx_stack_open(C.byref(h), int(self._signed), buf.ctypes.data, buf.size, offs.ctypes.data,
+                                        gs.ctypes.data if gs is not None else None, self._size,
                                         len(self._frame_sizes), self._block, 0, self._device))
             self._stack, self._stack_len = h, len(self._data)
         check(lib().trpx_stack_read(self._stack, frame, _code(out.dtype, True), out.ctypes.data))
         return out
+
+    def _states(self):
+        """The group states if they belong to the object's current frames, else None."""
+        groups = lib().trpx_group_count(self._size, self._block) if self._size else 0
+        gs = self._group_states
+        return gs if gs is not None and groups and gs.size == groups * len(self._frame_sizes) else None
+
+    def has_group_index(self) -> bool:
+        return self._states() is not None
 
     def _drop_stack(self) -> None:
         if getattr(self, "_stack", None) is not None:
@@ -141,8 +154,10 @@ class Terse:
         out = np.empty((f, self._size), np.dtype(dtype))
         buf = np.frombuffer(self._data, np.uint8)
         offs = np.concatenate([[0], np.cumsum(self._frame_sizes)]).astype(np.uint64)
-        check(lib().trpx_decode_host(int(self._signed), _code(dtype, True), buf.ctypes.data, buf.size, offs.ctypes.data,
-                                     self._size, f, self._block, out.ctypes.data, self._device))
+        gs = self._states()
+        check(lib().trpx_decode_host_grouped(int(self._signed), _code(dtype, True), buf.ctypes.data, buf.size, offs.ctypes.data,
+                                             gs.ctypes.data if gs is not None else None, self._size, f, self._block,
+                                             out.ctypes.data, self._device))
         return out
 
     # ---- accessors (Terse.hpp:396-444) --------------------------------------------------------
@@ -181,8 +196,9 @@ class Terse:
 
     # ---- stream-serialise surface (Terse.hpp:454-474, :279, :485-498) -----------------------
     def header(self, frame_index: bool = False) -> bytes:
-        """Header text of ``write`` (Terse.hpp:454-470).  ``frame_index=True`` adds the ``frame_sizes`` attribute
-        (SURVEY.md section 8 row f1): ignored by the reference reader, lets ``read`` skip the device walk."""
+        """Header text of ``write`` (Terse.hpp:454-470).  ``frame_index=True`` adds the ``frame_sizes`` and
+        ``group_bit_offsets`` attributes: ignored by the reference reader, they let ``read``
+        locate the frames and ``prolix`` expand them without any header walk."""
         h = _lib.trpx_header()
         h.prolix_bits, h.is_signed, h.block = self._prolix_bits, int(self._signed), self._block
         h.memory_size, h.number_of_values = len(self._data), self._size
@@ -190,9 +206,24 @@ class Terse:
         h.n_dims = len(self._dim)
         for i, d in enumerate(self._dim[:8]):
             h.dims[i] = d
-        cap = 512 + (21 * len(self._frame_sizes) if frame_index else 0)
+        gs = None
+        if frame_index and self._frame_sizes and lib().trpx_group_count(self._size, self._block):
+            gs = self._states()
+            if gs is None:                                   # compute them once: one walk of the stack on the device
+                data = np.frombuffer(self._data, np.uint8)
+                offs = np.concatenate([[0], np.cumsum(self._frame_sizes)]).astype(np.uint64)
+                gs = np.zeros(lib().trpx_group_count(self._size, self._block) * len(self._frame_sizes), np.uint64)
+                max_bits = 8 if self._prolix_bits <= 8 else 16 if self._prolix_bits <= 16 else 32
+                check(lib().trpx_group_states_host(data.ctypes.data, data.size, offs.ctypes.data, self._size, len(self._frame_sizes),
+                                                   self._block, max_bits, gs.ctypes.data, self._device))
+                del data
+                self._group_states = gs
+        cap = 512 + (21 * len(self._frame_sizes) + (16 * gs.size if gs is not None else 0) if frame_index else 0)
         buf = C.create_string_buffer(cap)
-        if frame_index:
+        if frame_index and gs is not None:
+            sizes = np.asarray(self._frame_sizes, np.uint64)
+            n = lib().trpx_header_format_grouped(C.byref(h), sizes.ctypes.data, sizes.size, gs.ctypes.data, gs.size, buf, cap)
+        elif frame_index:
             sizes = np.asarray(self._frame_sizes, np.uint64)
             n = lib().trpx_header_format_indexed(C.byref(h), sizes.ctypes.data, sizes.size, buf, cap)
         else:
@@ -248,4 +279,9 @@ class Terse:
             if int(offs[-1]) != len(t._data):
                 raise ValueError("frame chain does not cover the payload (corrupt .trpx)")
             t._frame_sizes = [int(x) for x in np.diff(offs)]
+        groups = lib().trpx_group_count(t._size, t._block) if t._size else 0
+        if groups and t._frame_sizes:                        # row f1: group states, if the file has them (checked on the device when used)
+            gs = np.zeros(groups * len(t._frame_sizes), np.uint64)
+            if lib().trpx_header_group_states(blob, off.value, gs.ctypes.data, gs.size) == gs.size:
+                t._group_states = gs
         return t
