@@ -10,7 +10,7 @@ blocks, cur = [], ["entry", {}]
 tot = {}
 for l in lines[start + 1:]:
     s = l.strip()
-    if s.startswith("s_endpgm"):
+    if s.startswith(".Lfunc_end"):
         break
     m = re.match(r"^(\.LBB\d+_\d+):", s)
     if m:

@@ -272,7 +272,10 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
                          block == (unsigned)trpx::kBlock;
     // many small frames: one workgroup per frame, the walk and the extraction overlap inside it;
     // few large frames: the tiled kernels (the walk is then the whole critical path either way)
-    if (fast_ok && !force_tiles && (force_frames || n_frames >= 128))
+    // (the per-frame decoder packs a block's bit position with its width into 32 bits: frames of < 2^26 bits less the
+    // walker's ring offset and one step's overshoot)
+    const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
+    if (fast_ok && frame26 && !force_tiles && (force_frames || n_frames >= 128))
         HIP_TRY(trpx::launch_decode_frames(out_dtype, a, static_cast<hipStream_t>(stream)));
     else if (fast_ok)
         HIP_TRY(trpx::launch_decode_fast(out_dtype, a, false, static_cast<hipStream_t>(stream)));

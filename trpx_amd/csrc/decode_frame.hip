@@ -3,19 +3,22 @@
 // Replaces jpa::Terse::prolix(Iterator, frame) (reference include/Terse.hpp:352-389) and
 // Bit_range::get_range / operator T() (Bit_pointer.hpp:742-792, :597-617).
 //
-//   wave 0 ("walker")    walks the frame's header chain (Terse.hpp:360-372) exactly like k_walk_lds --
-//                        64 candidate blocks per step, stream staged through a private LDS window --
-//                        but deposits width[b] and the 64-block group offsets in LDS instead of HBM.
-//   waves 1-3            one super-step (768 blocks = 12 groups of 64) behind the walker: each wave takes four
-//                        groups; every lane loads the stream dwords of its own block straight from L2 (the
-//                        walker has just pulled them through), extracts the 12 fields with width-specialised
-//                        code on registers and stores the pixels (24/48 bytes per lane, non-temporal).
-//   one barrier per super-step; width buffers are double buffered.
+//   one wave ("walker")  walks the frame's header chain (Terse.hpp:360-372): 64 candidate blocks per step, one step per
+//                        run of equal widths, the stream staged through a private 8 KB LDS window (refilled by LDS-DMA,
+//                        no staging registers).  For every block it leaves "bit position of the first payload bit |
+//                        width << 26" in LDS.
+//   three waves          one super-step (768 blocks = 12 groups of 64) behind the walker: each wave takes four groups;
+//                        every lane loads the stream dwords of its own block straight from L2 (the walker has just
+//                        pulled them through) at the position the walker left, extracts the 12 fields with
+//                        width-specialised code on registers and stores the pixels (12 / 24 bytes per lane,
+//                        non-temporal; 32-bit pixels go through a per-wave LDS row and leave as whole lines).
+//   one barrier per super-step; the position buffers are double buffered.
 //
-// The walk is the critical path (serial by construction of the format); the extraction hides under it.
+// The walk is the critical path (serial by construction of the format); the extraction hides under it as far as the
+// CU's shared issue resources allow.
 // HBM traffic per frame: S read (once from HBM, once more from L2) + N*sizeof(T) written = algorithmic.
 // Best for many small frames (one workgroup each); few huge frames are better served by the tiled
-// kernels of decode_fast.hip with a decode index.
+// kernels of decode_fast.hip.
 #include "codec_common.hpp"
 #include "encode_kernels.hpp"
 #include "profile.hpp"
@@ -23,47 +26,78 @@
 
 namespace trpx {
 
-#ifndef TRPX_FRAME_WAVES
-#define TRPX_FRAME_WAVES 4
-#endif
+constexpr int kFrameWaves = 4;                          // waves per workgroup: 1 walker + 3 extraction waves
+constexpr int kFrameThreads = kFrameWaves * kWave;
+
 #ifndef TRPX_FRAME_GPW
 #define TRPX_FRAME_GPW 4
 #endif
-constexpr int kFrameWaves = TRPX_FRAME_WAVES;           // waves per workgroup: 1 walker + (kFrameWaves - 1) unpackers
-constexpr int kFrameThreads = kFrameWaves * kWave;
-constexpr int kGroupsPerWave = TRPX_FRAME_GPW;          // 64-block groups per unpack wave and super-step
-constexpr int kStepGroups = (kFrameWaves - 1) * kGroupsPerWave;   // 64-block groups per super-step
-constexpr int kStepBlocks = kStepGroups * kWave;       // 768
 #ifndef TRPX_FRAME_CHUNK_DW
 #define TRPX_FRAME_CHUNK_DW 2048
 #endif
-constexpr int kFrameChunkDw = TRPX_FRAME_CHUNK_DW;     // walker's stream window: 8 KB.  Stream cache-resident (decode after decode): 2 / 4 / 8 /
-                                                       // 16 KB -> 0.31 / 0.32 / 0.30 / 0.30 ms; cold (decode after an encode, the bench's round
-                                                       // trip): 0.40 / 0.37 / 0.35 / 0.40 ms -- the unpack waves re-read the window's lines from
-                                                       // L2, and 250 workgroups per XCD x 16 KB is all of its 4 MB
+template <typename T>
+struct FrameCfg {
+    static constexpr int kGpw = TRPX_FRAME_GPW;                          // 64-block groups per extraction wave and super-step
+    static constexpr int kStepGroups = (kFrameWaves - 1) * kGpw;
+    static constexpr int kStepBlocks = kStepGroups * kWave;              // 768
+    // walker's stream window: 8 KB.  Stream cache-resident (decode after decode): 2 / 4 / 8 / 16 KB -> 0.31 / 0.32 / 0.30 /
+    // 0.30 ms; cold (decode after an encode, the bench's round trip): 0.40 / 0.37 / 0.35 / 0.40 ms -- the extraction waves
+    // re-read the window's lines from L2, and 250 workgroups per XCD x 16 KB is all of its 4 MB
+    static constexpr int kChunkDw = TRPX_FRAME_CHUNK_DW;
+    static constexpr bool kOutStaged = sizeof(T) == 4;                   // 32-bit pixels: through the wave's LDS row, 16 bytes per lane and store
+    static constexpr int kRawDw = 4 * RawQuads<T>::n;                    // stream dwords a lane loads for its block
+    static constexpr int kOutDw = kWave * kBlock * (int)sizeof(T) / 4;   // an extraction wave's output row: 64 blocks of pixels
+    static_assert(kChunkDw % (kWave * 4) == 0, "window = whole 1 KB pieces");
+};
+
+// One LDS-DMA piece: lane l's 16 bytes at `src` land at LDS byte address lds_base + 16 * l; no staging registers.  The
+// caller waits with s_waitcnt vmcnt(0) before it reads the bytes.  (An asm statement: with the builtin in the kernel's body
+// the host pass of hipcc 7.2 silently dropped the kernel's launch stubs.)
+__device__ __forceinline__ void lds_dma16(const uint32_t* src, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
 
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
                                                                uint32_t* __restrict__ status) {
+    using Cfg = FrameCfg<T>;
+    constexpr int kGroupsPerWave = Cfg::kGpw, kStepBlocks = Cfg::kStepBlocks, kChunkDw = Cfg::kChunkDw;
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
-    __shared__ uint32_t s_chunk[kFrameChunkDw + 4];    // walker's window of the stream
-    __shared__ uint8_t s_w[2][kStepBlocks + 68];       // [0] = width of the block before the super-step, [1 + i] = widths of its blocks (double buffered); 64 spare bytes behind (fast steps)
-    __shared__ uint32_t s_goff[3][kStepGroups < kWave ? kWave : kStepGroups];   // [0..1]: frame-relative bit offset of each group's first block; [2]: spare row (fast steps)
-    uint8_t* const s_wb = &s_w[0][0];
-    uint32_t* const s_goffx = &s_goff[0][0];
-    constexpr uint32_t kGoffRow = kStepGroups < kWave ? kWave : kStepGroups;
-    constexpr bool kStaged = sizeof(T) == 4;           // (8/16-bit pixels: direct stores are as fast -- int8 stacks 0.24 direct / 0.26 ms staged)
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][kStaged ? kWave * kBlock * sizeof(T) / 4 : 4];   // a group's pixels, per extraction wave
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kChunkDw + 4];  // walker's window of the stream
+    // per block: bit position of its first payload bit (relative to dword frame_dw, 26 bits) | width << 26 (double buffered).  [0] = the
+    // width of the block before the super-step, [1 + i] = its blocks, 64 spare entries behind (fast steps)
+    __shared__ uint32_t s_pos[2][kStepBlocks + 68];
+    uint32_t* const s_posx = &s_pos[0][0];
+    constexpr uint32_t kPosBits = 26, kPosMask = (1u << kPosBits) - 1u;
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][Cfg::kOutStaged ? Cfg::kOutDw : 4];  // a group's pixels, per extraction wave
     __shared__ uint32_t s_err;
+    __shared__ uint32_t s_role[kFrameWaves];
 
     const uint32_t lane = (uint32_t)lane_id();
-    const int wave = wave_id();
+    const int hw_wave = wave_id();
     const uint64_t frame = blockIdx.x;
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     if (threadIdx.x == 0) s_err = (fe > fo && fe <= terse_bytes) ? 0u : 1u;
+    // Which wave walks.  A workgroup's four waves land on the CU's four SIMDs, the first one on a SIMD that rotates from
+    // workgroup to workgroup, and the k-th workgroup to arrive on a CU gets wave slot k on every SIMD (measured,
+    // tools/hwid.hip).  "The wave whose SIMD number equals its slot number mod 4 walks" puts exactly two of a CU's eight
+    // walkers on every SIMD; with "wave 0 walks" they are spread at random, up to five on one SIMD (3 % slower).  (HW_ID: slot =
+    // bits 3:0, SIMD = bits 5:4.)  If no wave or more than one matches -- another placement -- the lowest match, else wave 0.
+    {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (lane == 0) s_role[hw_wave] = ((hwid >> 4) & 3u) == (hwid & 3u) ? 1u : 0u;
+    }
     __syncthreads();
+    int walker_wave = 0;
+#pragma unroll
+    for (int i = kFrameWaves - 1; i >= 0; --i) walker_wave = s_role[i] ? i : walker_wave;
+    walker_wave = __builtin_amdgcn_readfirstlane(walker_wave);
+    const int wave = (hw_wave - walker_wave + kFrameWaves) % kFrameWaves;     // role: 0 walks, 1.. extract (wave-uniform scalar)
     if (s_err) {
         if (threadIdx.x == 0) atomicMax(&status[0], 5u);
         return;
@@ -80,62 +114,64 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
     const uint32_t n_steps = (n_blocks + kStepBlocks - 1) / kStepBlocks;
     T* __restrict__ fout = pixels_out + frame * g.n_values;
 
-    // walker state (wave 0 only; wave-uniform)
-    int32_t c_lo = 0, c_hi = 0;
+#ifdef TRPX_DEC_NO_STORE
+    uint32_t diag_acc = 0;
+#endif
+    // walker state (wave-uniform)
+    int32_t c_lo = 0, c_hi = 0;                        // the window holds dwords [c_lo, c_hi) of the frame
     uint32_t b = 0, w_prev = 0, pos = 0, final_pos = 0;
     if (wave == 0) __builtin_amdgcn_s_setprio(3);      // the walk is the critical path
 
+#ifdef TRPX_DEC_STAMPS
+    uint64_t st_work = 0, st_wait = 0, st_t0 = __builtin_readcyclecounter(), st_start = st_t0;
+#endif
     for (uint32_t s = 0; s <= n_steps; ++s) {
         if (wave == 0) {
             if (s < n_steps) {
                 const uint32_t buf = s & 1u;
                 const uint32_t end_b = (s + 1) * kStepBlocks < n_blocks ? (s + 1) * kStepBlocks : n_blocks;
-                if (lane == 0) s_w[buf][0] = (uint8_t)w_prev;
+                if (lane == 0) s_pos[buf][0] = w_prev << kPosBits;
                 bool bad = false;
                 const uint32_t fast_end = end_b < n_blocks ? end_b : n_blocks - 1;   // the frame's last block: general step
                 while (b < end_b) {
-                    // ---- fast steps: 64 real candidates, all inside this super-step and inside the LDS window ------------
-                    // The step's serial chain is short: address -> LDS read -> ballot -> s_ff1 -> two v_readlane -> a few
-                    // scalar adds.  Every lane decodes "its" explicit header in parallel (Terse.hpp:362-370), so the
-                    // block that ends the run only has to be picked, not parsed.  (Also consuming the block AFTER that one
-                    // in the same step -- an isolated odd block is two explicit headers in a row -- cut the steps per
-                    // synth-v1 frame from 602 to 436 but made each step 40 % longer: no gain, not kept.  For streams whose width
-                    // changes every block or two, a scalar block-by-block walk over 64 dwords held in VGPRs -- two v_readlane,
-                    // a 64-bit shift, the header decode, v_writelane of the width: ~25 instructions per block -- was measured
-                    // too: 3.7 ms instead of 3.2 ms per noisy 2000-frame stack; dependent scalar chains run at ~15 clocks per
-                    // instruction here.)
+                    // ---- fast steps: 64 candidates inside the LDS window ----------------------------------------------------
+                    // One step = one run of equal widths + the explicit header behind it (or the super-step's last block).
+                    // The step's serial chain: position -> LDS read -> ballot -> s_ff1 -> two v_readlane -> a few scalar
+                    // adds.  Every lane decodes "its" explicit header before the ballot resolves (Terse.hpp:362-370), so the
+                    // block that ends the run only has to be picked, not parsed; the store (first payload bit | width, for the
+                    // extraction waves) is unconditional: lanes behind the step's last block write values the next step
+                    // overwrites.  One branch per step.  (Measured and dropped: consuming the block AFTER the explicit one in
+                    // the same step, 602 -> 436 steps per synth-v1 frame but each 40 % longer; a scalar block-by-block walk for
+                    // header-dense streams, 3.7 instead of 3.2 ms per noisy stack; decoding the header on the scalar unit
+                    // after the pick, 15 instead of 30 vector but 46 instead of 31 scalar instructions: no faster; a ring of
+                    // LDS slots with the next slot(s) in flight instead of this window: the walker alone 5-10 % faster, the
+                    // whole kernel 5-15 % slower)
                     {
                         uint32_t stride = 1u + kBlock * w_prev;
                         int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
                         uint32_t wide = 0;                                // widest explicit block of these steps (checked once, after them)
-                        const uint32_t wbase = (uint32_t)(buf * (kStepBlocks + 68)) + 1u - s * kStepBlocks;   // s_w index of block 0
-                        while (b + 64u <= fast_end && (int32_t)pos < pos_max) {
-                            // One step = one run of equal widths + the explicit header behind it.  Everything that does not
-                            // need `first` is issued before the ballot (every lane decodes "its" explicit header,
-                            // Terse.hpp:362-370), the step has one branch (the loop's), and the width / group-offset stores
-                            // are unconditional: lanes behind the step's last block write values the next step overwrites,
-                            // lanes that start no 64-block group write to a spare row.  (Walker alone: 0.23 -> 0.20 ms per
-                            // 2000-frame stack against the branchy version.)
+                        const uint32_t pbase = (uint32_t)(buf * (kStepBlocks + 68)) + 1u - s * kStepBlocks;   // s_pos index of block 0
+                        while (b < fast_end && (int32_t)pos < pos_max) {
                             const uint32_t lpos = pos + __umul24(lane, stride);
                             const uint32_t fbit = frame_sh - 32u * (uint32_t)c_lo + lpos;
                             const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
                             const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
                             const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
-                            const uint32_t advk = (w3 != 7u ? 4u : (wa != 10u ? 6u : 12u)) + kBlock * wk;   // header + payload bits
+                            const uint32_t hlk = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
+                            const uint32_t advk = hlk + kBlock * wk;                                    // header + payload bits
                             const uint64_t stop = ~__ballot((bits & 1u) != 0u);                           // Terse.hpp:361
                             const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                            const bool run = first >= 64u;                                              // all 64 repeat w_prev
+                            const uint32_t room = fast_end - b;                                         // the super-step's last block ends the step at the latest
+                            const uint32_t lim = room < 64u ? room : 64u;
+                            const bool run = first >= lim;                                              // all `lim` blocks repeat w_prev
                             const uint32_t src = run ? 63u : first;
                             const uint32_t x_w = (uint32_t)__builtin_amdgcn_readlane((int)wk, (int)src);
                             const uint32_t x_adv = (uint32_t)__builtin_amdgcn_readlane((int)advk, (int)src);
-                            const uint32_t e_w = run ? w_prev : x_w, adv = run ? 0u : x_adv;
+                            const uint32_t e_w = run ? w_prev : x_w;
                             wide = e_w > wide ? e_w : wide;
-                            const uint32_t n_done = run ? 64u : first + 1u;
-                            s_wb[wbase + b + lane] = (uint8_t)(lane < first ? w_prev : e_w);
-                            const uint32_t rl = b - s * kStepBlocks + lane;
-                            s_goffx[(rl & (kWave - 1)) == 0 && lane < n_done ? buf * kGoffRow + (rl >> 6) : 2 * kGoffRow + lane] = lpos;
-                            pos += first * stride + adv;                                                // (bounded by pos_max: inside the window)
-                            b += n_done;
+                            s_posx[pbase + b + lane] = frame_sh + lpos + (lane < first ? 1u + (w_prev << kPosBits) : hlk + (wk << kPosBits));
+                            pos += run ? lim * stride : first * stride + x_adv;                         // (bounded by pos_max: inside the window)
+                            b += run ? lim : first + 1u;
                             w_prev = e_w;
                             stride = 1u + kBlock * e_w;
                             pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;
@@ -143,22 +179,23 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         if (wide > kMaxW) bad = true;                     // a corrupt header: at worst the steps above wrote bogus widths to LDS
                         if (bad || b >= end_b) break;
                     }
+                    // ---- general step: refills the window; the frame's last block(s) -------------------------------------
                     const uint32_t stride = 1u + kBlock * w_prev;
                     const uint32_t need_lo = (frame_sh + pos) >> 5;
                     const uint32_t need_hi = ((frame_sh + pos + 63u * stride) >> 5) + 2;
                     if ((int32_t)need_lo < c_lo || (int32_t)need_hi > c_hi) {       // refill the window
                         c_lo = (int32_t)(((frame_dw + need_lo) & ~3ull) - frame_dw);
-                        c_hi = c_lo + kFrameChunkDw;
+                        c_hi = c_lo + kChunkDw;
                         const uint64_t d0 = (uint64_t)((int64_t)frame_dw + c_lo);
-                        if (base16 && (d0 & 3) == 0 && d0 + kFrameChunkDw <= n_dw) {
-                            constexpr int kIt = kFrameChunkDw / (kWave * 4);
-                            uint4 x[kIt];
+                        if (base16 && (d0 & 3) == 0 && d0 + kChunkDw <= n_dw) {
+                            // straight into LDS (LDS-DMA: 1 KB per instruction, destination = wave-uniform base + lane * 16):
+                            // no staging registers
 #pragma unroll
-                            for (int it = 0; it < kIt; ++it) x[it] = *reinterpret_cast<const uint4*>(s32 + d0 + it * kWave * 4 + lane * 4);
-#pragma unroll
-                            for (int it = 0; it < kIt; ++it) *reinterpret_cast<uint4*>(&s_chunk[it * kWave * 4 + lane * 4]) = x[it];
+                            for (int it = 0; it < kChunkDw / (kWave * 4); ++it)
+                                lds_dma16(s32 + d0 + it * kWave * 4 + lane * 4, (uint32_t)(uintptr_t)&s_chunk[it * kWave * 4]);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         } else {
-                            for (uint32_t i = lane * 4; i < (uint32_t)kFrameChunkDw; i += kWave * 4) {
+                            for (uint32_t i = lane * 4; i < (uint32_t)kChunkDw; i += kWave * 4) {
                                 const uint64_t d = d0 + i;
                                 uint4 x;
                                 x.x = d < n_dw ? s32[d] : 0u; x.y = d + 1 < n_dw ? s32[d + 1] : 0u;
@@ -166,15 +203,17 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                                 *reinterpret_cast<uint4*>(&s_chunk[i]) = x;
                             }
                         }
+                        if (b < fast_end) continue;                                   // go on with fast steps
                     }
-                    const uint32_t fbit = frame_sh + pos + lane * stride - 32u * (uint32_t)c_lo;
+                    const uint32_t lpos = pos + lane * stride;
+                    const uint32_t fbit = frame_sh + lpos - 32u * (uint32_t)c_lo;
                     const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
                     const uint32_t left = end_b - b;                                  // candidates inside this super-step
                     const uint64_t valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
                     const uint64_t same = __ballot((bits & 1u) != 0u) & valid;        // Terse.hpp:361
                     const uint64_t stop = ~same;
                     const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                    uint32_t e_w = w_prev, new_pos, new_b;
+                    uint32_t e_w = w_prev, new_pos, new_b, e_hl = 1;
                     if (first < left && first < 64u) {                                // explicit header at block b + first
                         const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, first);
                         uint32_t w = (eb >> 1) & 7u, hl = 4;                          // Terse.hpp:362-370
@@ -184,6 +223,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         }
                         if (w > kMaxW) { bad = true; break; }
                         e_w = w;
+                        e_hl = hl;
                         const uint32_t nbv = b + first + 1 == n_blocks ? nb_last : (uint32_t)kBlock;
                         new_pos = pos + first * stride + hl + nbv * w;
                         new_b = b + first + 1;
@@ -195,10 +235,8 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         new_b = b + cnt;
                     }
                     const uint32_t n_done = new_b - b, rel = b - s * kStepBlocks;
-                    if (lane < n_done) {
-                        s_w[buf][1 + rel + lane] = (uint8_t)(lane < first ? w_prev : e_w);
-                        if (((rel + lane) & (kWave - 1)) == 0) s_goff[buf][(rel + lane) >> 6] = pos + lane * stride;
-                    }
+                    if (lane < n_done)
+                        s_pos[buf][1 + rel + lane] = frame_sh + lpos + (lane < first ? 1u + (w_prev << kPosBits) : e_hl + (e_w << kPosBits));
                     pos = new_pos;
                     w_prev = e_w;
                     b = new_b;
@@ -210,15 +248,15 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 // A stream with an explicit header every few blocks costs this walker a step per header (10 x the time of a
                 // run-dominated frame); false chains merge quickly in such streams, so the frame goes to the
                 // position-parallel walk instead (decode_seg.hip).  Decided after super-steps 0, 3 and 11 on the width
-                // changes inside the super-step just walked (12 widths per lane, outside the step loop).  (Probing the first 256
-                // blocks instead -- a second bound in the fast loop -- hands a header-dense frame over after 0.06 instead of
-                // 0.13 ms but cost every other stack 6-60 %: the loop bound became loop-variant.)
+                // changes inside the super-step just walked (9 or 12 widths per lane, outside the step loop).  (Probing the
+                // first 256 blocks instead -- a second bound in the fast loop -- hands a header-dense frame over after 0.06
+                // instead of 0.13 ms but cost every other stack 6-60 %: the loop bound became loop-variant.)
                 if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_b == (s + 1) * kStepBlocks && end_b < n_blocks) {
                     uint32_t changes = 0;
 #pragma unroll
                     for (int i = 0; i < kStepBlocks / kWave; ++i) {
                         const uint32_t at = lane * (kStepBlocks / kWave) + i;
-                        changes += s_w[buf][at] != s_w[buf][at + 1] ? 1u : 0u;
+                        changes += (s_pos[buf][at] >> kPosBits) != (s_pos[buf][at + 1] >> kPosBits) ? 1u : 0u;
                     }
                     const uint32_t inc = wave_inclusive_scan(changes);
                     if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > (uint32_t)kStepBlocks && lane == 0) s_err = 2u;
@@ -229,47 +267,39 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
 #else
         } else if (s >= 1) {
 #endif
-            // ---- unpack super-step s-1: this wave's groups, one after the other ------------------------------------
+            // ---- extraction of super-step s-1: this wave's groups, one after the other ----------------------------------
             // Every lane loads the stream dwords of its own block straight from L2 (the walker has just pulled them
-            // through): one or more dwordx4 loads starting at the dword that holds the block's first payload bit, as many
-            // as the widest block of the group needs; the width-specialised bodies then work on registers only.
+            // through): dwordx4 loads starting at the dword that holds the block's first payload bit -- the walker left
+            // that position and the width in s_pos, so there is no scan here --, all kRawDw dwords whatever the widths (a
+            // 16-byte load more per lane is cheaper than a wavefront max of the widths, and the extra bytes are the
+            // neighbours').  The width-specialised bodies work on registers only and leave the packed pixels in registers;
+            // the stores follow once per group, behind all passes.  (Measured and dropped, DESIGN.md 4.3: the next group's
+            // loads issued before this group's stores -- a second register set, 64 VGPRs with spills; a group's bytes
+            // fetched into LDS by LDS-DMA and its pixels leaving through LDS rows as whole lines -- fewer, cheaper
+            // vector-memory instructions, but 60 % more scalar and LDS instructions: 0.39 instead of 0.29 ms.)
             const uint32_t pbuf = (s - 1) & 1u;
-            constexpr int NQ = RawQuads<T>::n;
+            constexpr int kRawDw = Cfg::kRawDw;
             const uint32_t* __restrict__ fbase = s32 + frame_dw;          // wave-uniform base; per-lane 32-bit dword offsets
+            const uint32_t step0 = (s - 1) * kStepBlocks;
+            const uint32_t g0 = (uint32_t)(wave - 1) * (uint32_t)kGroupsPerWave;
 #pragma unroll 1
             for (int gq = 0; gq < kGroupsPerWave; ++gq) {
-                const uint32_t gi = (uint32_t)(wave - 1) * (uint32_t)kGroupsPerWave + gq;
+                const uint32_t gi = g0 + gq;
+                if (step0 + gi * kWave >= n_blocks) break;                            // wave-uniform: group past the frame's end
                 const uint32_t rel = gi * kWave + lane;
-                const uint32_t blk = (s - 1) * kStepBlocks + rel;
-                if ((s - 1) * kStepBlocks + gi * kWave >= n_blocks) break;            // wave-uniform: group past the frame's end
-                uint32_t w = 0, hl = 0;
-                int nb = 0;
+                const uint32_t blk = step0 + rel;
+                uint32_t w = 0, q = frame_sh + limit;                                 // (lanes behind the frame's end: a position behind every block's)
                 if (blk < n_blocks) {
-                    w = s_w[pbuf][1 + rel];
-                    const uint32_t wp = s_w[pbuf][rel];
-                    hl = header_len(w, wp);
-                    nb = blk + 1 == n_blocks ? (int)nb_last : kBlock;
+                    const uint32_t pw = s_pos[pbuf][1 + rel];
+                    w = pw >> kPosBits;
+                    q = pw & kPosMask;                                                // first payload bit, relative to dword frame_dw
                 }
-
-                const uint32_t len = nb ? hl + __umul24((uint32_t)nb, w) : 0u;
-                const uint32_t inc = wave_inclusive_scan(len);
-#ifdef TRPX_DEC_NO_EXTRACT
-                if (inc == 0xFFFFFFFFu) fout[0] = (T)w;                               // (diagnostic build: no loads, no extraction, no stores)
-                continue;
-#endif
-                const uint32_t q = frame_sh + s_goff[pbuf][gi] + (inc - len) + hl;    // first payload bit, relative to dword frame_dw
                 const uint32_t dq = q >> 5, sq = q & 31u;
-                // (Issuing the NEXT group's loads before extracting this one was measured twice: a second set of raw registers
-                // means 64 VGPRs with spills at 8 workgroups per CU, 0.39 ms instead of 0.32 ms; only the first 16 bytes
-                // per lane in flight -- enough for widths <= 8 -- still 0.355 ms: the next group's width reads and scan
-                // in front of the extraction cost more than the exposed L2 round trip.)
-                // All NQ quads, whatever the widths: a 16-byte load more per lane is cheaper than a wavefront max of the
-                // widths, and the extra bytes are the neighbours' (same cache lines).
-                const uint32_t last_dw = (uint32_t)__builtin_amdgcn_readlane((int)dq, 63) + 4u * NQ;   // lanes ascend in position
-                uint32_t raw[4 * NQ];
+                const uint32_t last_dw = (uint32_t)__builtin_amdgcn_readlane((int)dq, 63) + (uint32_t)kRawDw;   // lanes ascend in position
+                uint32_t raw[kRawDw];
                 if (frame_dw + last_dw <= n_dw) {                                     // wave-uniform: the loads stay inside the stream
 #pragma unroll
-                    for (int i = 0; i < NQ; ++i) {
+                    for (int i = 0; i < kRawDw / 4; ++i) {
                         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                         u4 x4;
                         __builtin_memcpy(&x4, fbase + dq + 4 * i, 16);                 // dword-aligned 16-byte load
@@ -277,16 +307,21 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     }
                 } else {                                                              // the stack's last bytes: guarded element loads
 #pragma unroll
-                    for (int i = 0; i < 4 * NQ; ++i) {
+                    for (int i = 0; i < kRawDw; ++i) {
                         const uint64_t d = frame_dw + dq + i;
                         raw[i] = d < n_dw ? s32[d] : 0u;
                     }
                 }
+#ifdef TRPX_DEC_NO_EXTRACT
+                if (q == 0xFFFFFFFFu) fout[0] = (T)(w + raw[0]);                      // (diagnostic build: loads only)
+                continue;
+#endif
+                const bool full = blk + 1 < n_blocks || (blk + 1 == n_blocks && nb_last == (uint32_t)kBlock);
                 T* __restrict__ dst = fout + (uint64_t)blk * kBlock;
-                uint64_t todo = __ballot(nb == kBlock);
-                if (kStaged && todo == ~0ull) {
-                    // 64 full blocks: every lane leaves its 12 pixels in the wave's LDS row, then the wave stores the group
-                    // 16 bytes per lane -- whole lines per store instruction instead of 24-byte runs
+                uint64_t todo = __ballot(full);
+                if (Cfg::kOutStaged && todo == ~0ull) {
+                    // 64 full blocks of 32-bit pixels: every lane leaves its 12 pixels in the wave's LDS row, then the wave
+                    // stores the group 16 bytes per lane -- whole lines per store instruction instead of 48-byte runs
                     uint32_t* const stage = s_out[wave - 1];
                     uint32_t* const row = stage + lane * (kBlock * (uint32_t)sizeof(T) / 4u);
                     while (todo) {
@@ -301,23 +336,39 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    store_group<T>(stage, fout + (uint64_t)((s - 1) * kStepBlocks + gi * kWave) * kBlock);
+                    store_group<T>(stage, fout + (uint64_t)(step0 + gi * kWave) * kBlock);
                     __builtin_amdgcn_wave_barrier();                                  // (the row is rewritten by the next group)
-                    continue;
+                } else if constexpr (sizeof(T) == 4) {                                // 32-bit pixels, the frame's last group: stores inside the bodies
+                    while (todo) {
+                        const int l0 = __builtin_ctzll(todo);
+                        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                        const bool mine = full && w == w0;
+                        uint32_t ss = sq;
+                        asm volatile("" : "+v"(ss));
+                        if (mine) UnpackStoreDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, dst);
+                        todo &= ~__ballot(mine);
+                    }
+                } else {
+                    uint32_t o[PackedDwords<T>::n];
+                    while (todo) {
+                        const int l0 = __builtin_ctzll(todo);
+                        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                        const bool mine = full && w == w0;
+                        uint32_t ss = sq;
+                        asm volatile("" : "+v"(ss));                                  // keep the specialised bodies out of LICM's reach
+                        if (mine) UnpackRegsDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, o);
+                        todo &= ~__ballot(mine);
+                    }
+#ifdef TRPX_DEC_NO_STORE
+                    if (full) diag_acc ^= o[0];
+#else
+                    if (full) store_packed<T>(dst, o);
+#endif
                 }
-                while (todo) {
-                    const int l0 = __builtin_ctzll(todo);
-                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
-                    const bool mine = nb == kBlock && w == w0;
-                    uint32_t ss = sq;
-                    asm volatile("" : "+v"(ss));                                      // keep the specialised bodies out of LICM's reach
-                    if (mine) UnpackStoreDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, dst);
-                    todo &= ~__ballot(mine);
-                }
-                if (nb && nb != kBlock) {                                             // the frame's last, partial block
+                if (blk + 1 == n_blocks && !full) {                                   // the frame's last, partial block
                     const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
                     uint32_t p = q;
-                    for (int k = 0; k < nb; ++k) {
+                    for (uint32_t k = 0; k < nb_last; ++k) {
                         uint32_t f = 0;
                         if (w) {
                             const uint64_t d = frame_dw + (p >> 5);
@@ -331,9 +382,30 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 }
             }
         }
-        __syncthreads();                               // super-step boundary: widths of step s published, step s-1 consumed
+#ifdef TRPX_DEC_STAMPS
+        { const uint64_t t1 = __builtin_readcyclecounter(); st_work += t1 - st_t0; st_t0 = t1; }
+#endif
+        __syncthreads();                               // super-step boundary: positions of step s published, step s-1 consumed
+#ifdef TRPX_DEC_STAMPS
+        { const uint64_t t1 = __builtin_readcyclecounter(); st_wait += t1 - st_t0; st_t0 = t1; }
+#endif
         if (s_err) break;
     }
+#ifdef TRPX_DEC_STAMPS
+    // diagnostic build (tools/dec_stamps.py): per wave role, cycles spent working / waiting at the super-step barrier, and
+    // the wave's SIMD + slot; overwrites the first pixels of the frame
+    if (lane == 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        uint32_t* dbg = reinterpret_cast<uint32_t*>(fout) + 8 * wave;
+        dbg[0] = (uint32_t)st_work; dbg[1] = (uint32_t)st_wait; dbg[2] = hwid; dbg[3] = (uint32_t)(st_t0 - st_start);
+        dbg[4] = (uint32_t)(st_start & 0xFFFFFFFFu);
+        dbg[5] = dbg[6] = dbg[7] = 0;
+    }
+#endif
+#ifdef TRPX_DEC_NO_STORE
+    if (diag_acc == 0x12345678u) fout[threadIdx.x] = (T)diag_acc;
+#endif
     const bool deferred = s_err == 2u;
     if (s_err == 1u && threadIdx.x == 0) atomicMax(&status[0], 5u);        // TRPX_ERR_CORRUPT
     if (deferred && threadIdx.x == 0) defer[1u + atomicAdd(&defer[0], 1u)] = (uint32_t)frame;   // listed: k_seg_frames + k_unpack_listed do it
@@ -361,7 +433,7 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
 }
 
 // Preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned,
-// frames of < 2^32 bits.
+// frames of < 2^26 bits (less one step's overshoot).
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st) {
     switch (dtype) {
     case 0: return launch_decode_frames_t<uint8_t>(a, st);

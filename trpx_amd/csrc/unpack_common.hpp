@@ -137,6 +137,86 @@ __device__ __forceinline__ void unpack_store_w(const uint32_t (&raw)[4 * RawQuad
     }
 }
 
+// The same extraction into registers: the block's 12 pixels packed to the pixel type (3 / 6 / 12 dwords).  The caller
+// stores them after ALL specialised passes of a group: the number of store instructions per group is then static, which
+// lets a load issued before them (the next group's stream dwords) be awaited with s_waitcnt vmcnt(#stores) -- on gfx950
+// loads and stores retire through one in-order counter, so a store issued inside a data-dependent number of passes
+// would force vmcnt(0), i.e. a wait for the stores' round trip, in front of every group.
+template <typename T> struct PackedDwords { static constexpr int n = kBlock * (int)sizeof(T) / 4; };
+
+template <typename T, int W>
+__device__ __forceinline__ void unpack_regs_w(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t (&o)[PackedDwords<T>::n]) {
+    constexpr int bits = PixelTraits<T>::bits;
+    constexpr int NBITS = kBlock * W;
+    constexpr int ND = (NBITS + 31) / 32;
+    static_assert(ND + 1 <= 4 * RawQuads<T>::n, "field string must fit the loaded quads");
+    uint32_t x[ND ? ND : 1];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) x[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], s);   // string aligned to bit 0
+    uint32_t f[kBlock];
+#pragma unroll
+    for (int k = 0; k < kBlock; ++k) {
+        if constexpr (W == 0) f[k] = 0u;
+        else {
+            const int bit = k * W;
+            uint32_t y = x[bit >> 5] >> (bit & 31);
+            if ((bit & 31) + W > 32) y |= x[(bit >> 5) + 1] << (32 - (bit & 31));
+            if (PixelTraits<T>::is_signed) f[k] = (uint32_t)((int32_t)(y << (32 - W)) >> (32 - W));   // sign-extend (:784-789)
+            else f[k] = W >= 32 ? y : y & ((1u << (W & 31)) - 1u);
+        }
+    }
+    if constexpr (bits == 32) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[i] = f[i];
+    } else if constexpr (bits == 16) {                                               // v_perm_b32: {hi.lo16, lo.lo16}
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = __builtin_amdgcn_perm(f[2 * i + 1], f[2 * i], 0x05040100u);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t lo = __builtin_amdgcn_perm(f[4 * i + 1], f[4 * i], 0x0c0c0400u);       // {0, 0, b.byte0, a.byte0}
+            const uint32_t hi = __builtin_amdgcn_perm(f[4 * i + 3], f[4 * i + 2], 0x0c0c0400u);
+            o[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+    }
+}
+
+// A block's packed pixels -> memory: 12 bytes as 8 + 4, 24 bytes as 16 + 8, 48 bytes as 3 x 16 (non-temporal).
+template <typename T>
+__device__ __forceinline__ void store_packed(T* __restrict__ dst, const uint32_t (&o)[PackedDwords<T>::n]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    constexpr int bits = PixelTraits<T>::bits;
+    if constexpr (bits == 32) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u4 v = {o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst) + i);
+        }
+    } else if constexpr (bits == 16) {
+        u4 a = {o[0], o[1], o[2], o[3]};
+        u2 c = {o[4], o[5]};
+        __builtin_nontemporal_store(a, reinterpret_cast<u4*>(dst));
+        __builtin_nontemporal_store(c, reinterpret_cast<u2*>(dst) + 2);
+    } else {
+        u2 a = {o[0], o[1]};
+        __builtin_nontemporal_store(a, reinterpret_cast<u2*>(dst));                  // (4-byte aligned: block = 12 bytes)
+        __builtin_nontemporal_store(o[2], reinterpret_cast<uint32_t*>(dst) + 2);
+    }
+}
+
+template <typename T, int LO, int HI>
+struct UnpackRegsDispatch {
+    static __device__ __forceinline__ void run(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t w0, uint32_t (&o)[PackedDwords<T>::n]) {
+        if constexpr (LO == HI) unpack_regs_w<T, LO>(raw, s, o);
+        else {
+            constexpr int MID = (LO + HI) / 2;
+            if (w0 <= (uint32_t)MID) UnpackRegsDispatch<T, LO, MID>::run(raw, s, w0, o);
+            else UnpackRegsDispatch<T, MID + 1, HI>::run(raw, s, w0, o);
+        }
+    }
+};
+
 // The same extraction, but the block's 12 pixels go to the wavefront's LDS staging row instead of straight to memory
 // (`row` = staging + lane * 3 * sizeof(T) dwords, 8-byte aligned for 16/32-bit pixels): the wavefront then writes its
 // 64 blocks as whole 16-byte-per-lane stores (store_group), every store instruction covering consecutive bytes.
