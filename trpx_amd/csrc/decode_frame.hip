@@ -87,10 +87,12 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
     // tools/hwid.hip).  "The wave whose SIMD number equals its slot number mod 4 walks" puts exactly two of a CU's eight
     // walkers on every SIMD; with "wave 0 walks" they are spread at random, up to five on one SIMD (3 % slower).  (HW_ID: slot =
     // bits 3:0, SIMD = bits 5:4.)  If no wave or more than one matches -- another placement -- the lowest match, else wave 0.
+    uint32_t hw_slot = 0;
     {
         uint32_t hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         if (lane == 0) s_role[hw_wave] = ((hwid >> 4) & 3u) == (hwid & 3u) ? 1u : 0u;
+        hw_slot = hwid & 7u;
     }
     __syncthreads();
     int walker_wave = 0;
@@ -194,6 +196,9 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                             for (int it = 0; it < kChunkDw / (kWave * 4); ++it)
                                 lds_dma16(s32 + d0 + it * kWave * 4 + lane * 4, (uint32_t)(uintptr_t)&s_chunk[it * kWave * 4]);
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            // (Touching the window behind this one -- one dword of each of its lines by LDS-DMA into a scratch
+                            // row, so that the next refill finds them in L2: 1.5 % faster right behind an encode, 16 % slower
+                            // with the stream cache-resident: dropped.)
                         } else {
                             for (uint32_t i = lane * 4; i < (uint32_t)kChunkDw; i += kWave * 4) {
                                 const uint64_t d = d0 + i;
@@ -267,6 +272,13 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
 #else
         } else if (s >= 1) {
 #endif
+            // The SIMD's arbiter serves equal-priority waves oldest first: with all extraction waves at priority 0 the
+            // workgroups that arrived first on the CU finished after 0.17 ms, the last ones after 0.30 ms (tools/dec_stamps.py),
+            // a long tail with few waves left to hide latency.  Alternating the extraction waves' priority between 0 and 1
+            // from super-step to super-step, in opposite phase for odd and even wave slots, gives every workgroup the same
+            // share over time: all finish within 20 % of each other, the kernel 6 % sooner.  (Three levels, rotating the
+            // walkers' priority as well, or a rotation every second super-step: no better.)
+            if (((hw_slot + s) & 1u) != 0u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             // ---- extraction of super-step s-1: this wave's groups, one after the other ----------------------------------
             // Every lane loads the stream dwords of its own block straight from L2 (the walker has just pulled them
             // through): dwordx4 loads starting at the dword that holds the block's first payload bit -- the walker left
