@@ -113,7 +113,12 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
     const uint32_t frame_sh = (uint32_t)(frame_abit & 31);
     const uint32_t n_blocks = g.n_blocks;
     const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(n_blocks - 1) * kBlock);
-    const uint32_t n_steps = (n_blocks + kStepBlocks - 1) / kStepBlocks;
+    // Super-steps: step 0 is short when frames can be handed over (one group per extraction wave: the decision "this
+    // frame's headers are too dense for the serial walk" falls after 192 blocks instead of 768 -- a header-dense stack spends
+    // 0.04 instead of 0.11 ms here before its frames go to the position-parallel walk); every later step is kStepBlocks.
+    const uint32_t sb0 = defer ? (uint32_t)((kFrameWaves - 1) * kWave) : (uint32_t)kStepBlocks;
+    const uint32_t n_steps = n_blocks <= sb0 ? 1u : 1u + (n_blocks - sb0 + kStepBlocks - 1) / kStepBlocks;
+    auto step_begin = [&](uint32_t t) -> uint32_t { return t == 0u ? 0u : sb0 + (t - 1u) * kStepBlocks; };
     T* __restrict__ fout = pixels_out + frame * g.n_values;
 
 #ifdef TRPX_DEC_NO_STORE
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
         if (wave == 0) {
             if (s < n_steps) {
                 const uint32_t buf = s & 1u;
-                const uint32_t end_b = (s + 1) * kStepBlocks < n_blocks ? (s + 1) * kStepBlocks : n_blocks;
+                const uint32_t beg_b = step_begin(s);
+                const uint32_t end_b = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
                 if (lane == 0) s_pos[buf][0] = w_prev << kPosBits;
                 bool bad = false;
                 const uint32_t fast_end = end_b < n_blocks ? end_b : n_blocks - 1;   // the frame's last block: general step
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         uint32_t stride = 1u + kBlock * w_prev;
                         int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
                         uint32_t wide = 0;                                // widest explicit block of these steps (checked once, after them)
-                        const uint32_t pbase = (uint32_t)(buf * (kStepBlocks + 68)) + 1u - s * kStepBlocks;   // s_pos index of block 0
+                        const uint32_t pbase = (uint32_t)(buf * (kStepBlocks + 68)) + 1u - beg_b;             // s_pos index of block 0
                         while (b < fast_end && (int32_t)pos < pos_max) {
                             const uint32_t lpos = pos + __umul24(lane, stride);
                             const uint32_t fbit = frame_sh - 32u * (uint32_t)c_lo + lpos;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         new_pos = pos + cnt * stride;
                         new_b = b + cnt;
                     }
-                    const uint32_t n_done = new_b - b, rel = b - s * kStepBlocks;
+                    const uint32_t n_done = new_b - b, rel = b - beg_b;
                     if (lane < n_done)
                         s_pos[buf][1 + rel + lane] = frame_sh + lpos + (lane < first ? 1u + (w_prev << kPosBits) : e_hl + (e_w << kPosBits));
                     pos = new_pos;
@@ -256,15 +262,16 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 // changes inside the super-step just walked (9 or 12 widths per lane, outside the step loop).  (Probing the
                 // first 256 blocks instead -- a second bound in the fast loop -- hands a header-dense frame over after 0.06
                 // instead of 0.13 ms but cost every other stack 6-60 %: the loop bound became loop-variant.)
-                if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_b == (s + 1) * kStepBlocks && end_b < n_blocks) {
+                if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_b == step_begin(s + 1u) && end_b < n_blocks) {
+                    const uint32_t per = (end_b - beg_b) / kWave;                     // widths per lane (whole groups)
                     uint32_t changes = 0;
 #pragma unroll
                     for (int i = 0; i < kStepBlocks / kWave; ++i) {
-                        const uint32_t at = lane * (kStepBlocks / kWave) + i;
-                        changes += (s_pos[buf][at] >> kPosBits) != (s_pos[buf][at + 1] >> kPosBits) ? 1u : 0u;
+                        const uint32_t at = lane * per + i;
+                        if ((uint32_t)i < per) changes += (s_pos[buf][at] >> kPosBits) != (s_pos[buf][at + 1] >> kPosBits) ? 1u : 0u;
                     }
                     const uint32_t inc = wave_inclusive_scan(changes);
-                    if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > (uint32_t)kStepBlocks && lane == 0) s_err = 2u;
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > end_b - beg_b && lane == 0) s_err = 2u;
                 }
             }
 #ifdef TRPX_DEC_WALK_ONLY
@@ -292,10 +299,11 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
             const uint32_t pbuf = (s - 1) & 1u;
             constexpr int kRawDw = Cfg::kRawDw;
             const uint32_t* __restrict__ fbase = s32 + frame_dw;          // wave-uniform base; per-lane 32-bit dword offsets
-            const uint32_t step0 = (s - 1) * kStepBlocks;
-            const uint32_t g0 = (uint32_t)(wave - 1) * (uint32_t)kGroupsPerWave;
+            const uint32_t step0 = step_begin(s - 1u);
+            const uint32_t gpw = (step_begin(s) - step0) / (uint32_t)((kFrameWaves - 1) * kWave);   // groups per wave in this super-step: 1 or kGroupsPerWave
+            const uint32_t g0 = (uint32_t)(wave - 1) * gpw;
 #pragma unroll 1
-            for (int gq = 0; gq < kGroupsPerWave; ++gq) {
+            for (uint32_t gq = 0; gq < gpw; ++gq) {
                 const uint32_t gi = g0 + gq;
                 if (step0 + gi * kWave >= n_blocks) break;                            // wave-uniform: group past the frame's end
                 const uint32_t rel = gi * kWave + lane;

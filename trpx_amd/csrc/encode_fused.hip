@@ -734,6 +734,11 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
             const uint32_t m = kk0 & 3u;
             const u4* pad4 = reinterpret_cast<const u4*>(s_stage_pad) + (kk0 >> 2);
             u4* dst = reinterpret_cast<u4*>(out32 + d_first + al);
+#ifdef TRPX_ENC_PLAIN_STORES
+#define TRPX_STREAM_STORE(v, p) (*(p) = (v))
+#else
+#define TRPX_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 #define TRPX_FLUSH_GROUPS(M)                                                                                   \
             for (uint32_t gq = tid; gq < n4; gq += kThreads) {                                                 \
                 const u4 A = pad4[gq], B = pad4[gq + 1];                                                       \
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
                 x.y = __builtin_amdgcn_alignbit(e[M + 2], e[M + 1], sh);                                       \
                 x.z = __builtin_amdgcn_alignbit(e[M + 3], e[M + 2], sh);                                       \
                 x.w = __builtin_amdgcn_alignbit(e[M + 4], e[M + 3], sh);                                       \
-                __builtin_nontemporal_store(x, dst + gq);                                                      \
+                TRPX_STREAM_STORE(x, dst + gq);                                                                \
             }
             if (m == 0) { TRPX_FLUSH_GROUPS(0) } else if (m == 1) { TRPX_FLUSH_GROUPS(1) }
             else if (m == 2) { TRPX_FLUSH_GROUPS(2) } else { TRPX_FLUSH_GROUPS(3) }
