@@ -29,17 +29,18 @@ namespace trpx {
 constexpr int kFrameWaves = 4;                          // waves per workgroup: 1 walker + 3 extraction waves
 constexpr int kFrameThreads = kFrameWaves * kWave;
 
-#ifndef TRPX_FRAME_GPW
-#define TRPX_FRAME_GPW 4
-#endif
 #ifndef TRPX_FRAME_CHUNK_DW
 #define TRPX_FRAME_CHUNK_DW 2048
 #endif
 template <typename T>
 struct FrameCfg {
-    static constexpr int kGpw = TRPX_FRAME_GPW;                          // 64-block groups per extraction wave and super-step
+#ifdef TRPX_FRAME_GPW
+    static constexpr int kGpw = TRPX_FRAME_GPW;
+#else
+    static constexpr int kGpw = sizeof(T) == 4 ? 4 : 6;                  // 64-block groups per extraction wave and super-step (LDS: 18 / 24 KB per workgroup)
+#endif
     static constexpr int kStepGroups = (kFrameWaves - 1) * kGpw;
-    static constexpr int kStepBlocks = kStepGroups * kWave;              // 768
+    static constexpr int kStepBlocks = kStepGroups * kWave;              // 768 / 1152
     // walker's stream window: 8 KB.  Stream cache-resident (decode after decode): 2 / 4 / 8 / 16 KB -> 0.31 / 0.32 / 0.30 /
     // 0.30 ms; cold (decode after an encode, the bench's round trip): 0.40 / 0.37 / 0.35 / 0.40 ms -- the extraction waves
     // re-read the window's lines from L2, and 250 workgroups per XCD x 16 KB is all of its 4 MB
