@@ -348,10 +348,12 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     while (todo) {
                         const int l0 = __builtin_ctzll(todo);
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                        uint32_t wd = w0;
+                        asm volatile("" : "+s"(wd));                                  // (a copy the compiler cannot equate with the lanes' own w: the dispatch on it stays scalar)
                         const bool mine = w == w0;
                         uint32_t ss = sq;
                         asm volatile("" : "+v"(ss));                                  // keep the specialised bodies out of LICM's reach
-                        if (mine) UnpackStageDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, row);
+                        if (mine) UnpackStageDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, wd, row);
                         todo &= ~__ballot(mine);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -363,10 +365,12 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     while (todo) {
                         const int l0 = __builtin_ctzll(todo);
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                        uint32_t wd = w0;
+                        asm volatile("" : "+s"(wd));                                  // (a copy the compiler cannot equate with the lanes' own w: the dispatch on it stays scalar)
                         const bool mine = full && w == w0;
                         uint32_t ss = sq;
                         asm volatile("" : "+v"(ss));
-                        if (mine) UnpackStoreDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, dst);
+                        if (mine) UnpackStoreDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, wd, dst);
                         todo &= ~__ballot(mine);
                     }
                 } else {
@@ -374,10 +378,12 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     while (todo) {
                         const int l0 = __builtin_ctzll(todo);
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
+                        uint32_t wd = w0;
+                        asm volatile("" : "+s"(wd));                                  // (a copy the compiler cannot equate with the lanes' own w: the dispatch on it stays scalar)
                         const bool mine = full && w == w0;
                         uint32_t ss = sq;
                         asm volatile("" : "+v"(ss));                                  // keep the specialised bodies out of LICM's reach
-                        if (mine) UnpackRegsDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, w0, o);
+                        if (mine) UnpackRegsDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, wd, o);
                         todo &= ~__ballot(mine);
                     }
 #ifdef TRPX_DEC_NO_STORE
