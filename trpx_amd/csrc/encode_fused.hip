@@ -600,9 +600,12 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
             const int l0 = __builtin_ctzll(todo);
             const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wr, l0);
             const bool mine = full && wr == w0;
+            uint32_t wd = w0;
+            asm volatile("" : "+s"(wd));          // a copy the compiler cannot equate with the lanes' own width: with w0 itself it dispatched on
+                                                  // the VECTOR (14 v_cmp per round and exec-mask branches per tree level instead of scalar compares)
 #pragma unroll
             for (int i = 0; i < Raw<T>::dw; ++i) asm volatile("" : "+v"(v[r][i]));       // keep the bodies out of LICM's reach
-            if (mine) PackDispatch<T, 0, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, hv_top, w0, v[r]);
+            if (mine) PackDispatch<T, 0, PixelTraits<T>::bits>::run(s_stage_pad, pos + hl, hv_top, wd, v[r]);
             todo &= ~__ballot(mine);
         }
         TRPX_WSTAMP(1 + r);

@@ -103,9 +103,11 @@ __device__ __forceinline__ bool unpack_tile(const uint8_t* __restrict__ terse, u
             const int l0 = __builtin_ctzll(todo);
             const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w[r], l0);
             const bool mine = nb[r] == kBlock && w[r] == w0;
+            uint32_t wd = w0 > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w0;
+            asm volatile("" : "+s"(wd));                    // (a copy the compiler cannot equate with the lanes' own width: the dispatch stays scalar)
             uint32_t qq = q;
             asm volatile("" : "+v"(qq));                    // keep the specialised bodies out of LICM's reach
-            if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(s_image, qq, w0 > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w0, u);
+            if (mine) UnpackDispatch<T, 1, PixelTraits<T>::bits>::run(s_image, qq, wd, u);
             todo &= ~__ballot(mine);
         }
         if (unpack_staged<T>() && __ballot(nb[r] == kBlock) == ~0ull) {   // the wavefront's 64 blocks are all full: staged, coalesced stores
