@@ -34,8 +34,8 @@ namespace trpx {
 
 namespace detail {
 template <typename T> constexpr int dtype_of() {
-    static_assert(std::is_integral_v<T> && sizeof(T) <= 4, "trpx::Terse: pixel type must be an integer of <= 32 bits");
-    return (sizeof(T) == 1 ? TRPX_U8 : sizeof(T) == 2 ? TRPX_U16 : TRPX_U32) + (std::is_signed_v<T> ? 1 : 0);
+    static_assert(std::is_integral_v<T> && sizeof(T) <= 8, "trpx::Terse: pixel type must be an integer of <= 64 bits");
+    return (sizeof(T) == 1 ? TRPX_U8 : sizeof(T) == 2 ? TRPX_U16 : sizeof(T) == 4 ? TRPX_U32 : TRPX_U64) + (std::is_signed_v<T> ? 1 : 0);
 }
 // output types of prolix(): the pixel types plus float / double (Terse.hpp:379-383)
 template <typename T> constexpr int out_dtype_of() {
@@ -197,7 +197,7 @@ public:
             std::vector<std::uint64_t> offs(sizes.size() + 1, 0);
             for (std::size_t f = 0; f < sizes.size(); ++f) offs[f + 1] = offs[f] + sizes[f];
             d_group_states.assign(groups * sizes.size(), 0);
-            const unsigned max_bits = d_prolix_bits <= 8 ? 8 : d_prolix_bits <= 16 ? 16 : 32;
+            const unsigned max_bits = d_prolix_bits <= 8 ? 8 : d_prolix_bits <= 16 ? 16 : 32;   // (wider data: trpx_group_states_host refuses, no group index)
             detail::check(trpx_group_states_host(d_terse_data.data(), d_terse_data.size(), offs.data(), d_size, sizes.size(), d_block,
                                                  max_bits, d_group_states.data(), -1), "Terse::write");
         }
@@ -238,23 +238,27 @@ private:
         using V = typename std::iterator_traits<Iterator>::value_type;
         f_drop_stack();
         d_group_states.clear();
+        bool narrowed = false;
         if constexpr (sizeof(V) == 8) {
             // 64-bit integers (what src/terse.cpp:120-123 makes of float / double images): the stream of values that fit
-            // 32 bits is the same whatever the container's type, so they are narrowed here; wider values are refused --
-            // the device path has no 64-bit fields.
+            // 32 bits is the same whatever the container's type, so they are narrowed here and take the tuned kernels;
+            // a stack with wider values goes through as 64-bit pixels (generic kernels, fields of up to 64 bits).
             static_assert(std::is_integral_v<V>, "trpx::Terse: pixel type must be integral");
             using N = std::conditional_t<std::is_signed_v<V>, std::int32_t, std::uint32_t>;
             std::vector<N> narrow(d_size * n_frames);
             Iterator it = data;
+            bool fits = true;
             for (N& x : narrow) {
                 const V v = *it++;
-                if (v < (V)std::numeric_limits<N>::min() || v > (V)std::numeric_limits<N>::max())
-                    throw std::invalid_argument("Terse::push_back: a 64-bit value needs more than 32 bits (not supported on the GPU path)");
+                if (v < (V)std::numeric_limits<N>::min() || v > (V)std::numeric_limits<N>::max()) { fits = false; break; }
                 x = (N)v;
             }
-            f_compress(narrow.data(), n_frames);
-            return;
-        } else {
+            if (fits) {
+                f_compress(narrow.data(), n_frames);
+                narrowed = true;
+            }
+        }
+        if (!narrowed) {
         std::vector<V> tmp;
         const V* src;
         if constexpr (std::is_pointer_v<Iterator>) src = data;
@@ -318,7 +322,7 @@ private:
             d_frame_sizes.assign(sizes.begin(), sizes.end());                      // row f1: the file carries its frame index
         else if (h.number_of_frames > 1) {
             std::vector<std::uint64_t> offs(h.number_of_frames + 1);
-            const unsigned max_bits = h.prolix_bits <= 8 ? 8 : h.prolix_bits <= 16 ? 16 : 32;
+            const unsigned max_bits = h.prolix_bits <= 8 ? 8 : h.prolix_bits <= 16 ? 16 : h.prolix_bits <= 32 ? 32 : 64;
             detail::check(trpx_frame_offsets_host(d_terse_data.data(), d_terse_data.size(), d_size, h.number_of_frames,
                                                   d_block, max_bits, offs.data(), -1), "Terse(std::ifstream&)");
             for (std::size_t f = 0; f < h.number_of_frames; ++f) d_frame_sizes.push_back(std::size_t(offs[f + 1] - offs[f]));

@@ -46,7 +46,10 @@ typedef enum trpx_status {
 /* Pixel types = the reference CLI's dispatch set (src/terse.cpp:113-118). Odd = signed. */
 typedef enum trpx_dtype {
     TRPX_U8 = 0, TRPX_I8 = 1, TRPX_U16 = 2, TRPX_I16 = 3, TRPX_U32 = 4, TRPX_I32 = 5,
-    TRPX_F32 = 6, TRPX_F64 = 7      /* output types of trpx_decode_convert / trpx_decode_host only */
+    TRPX_F32 = 6, TRPX_F64 = 7,     /* output types of trpx_decode_convert / trpx_decode_host only */
+    TRPX_U64 = 8, TRPX_I64 = 9      /* 64-bit containers (what src/terse.cpp:120-123 makes of float / double images; Terse.hpp:249
+                                     * takes any integral type): correct-first generic kernels, fields of up to 64 bits, no decode
+                                     * index; as an output type: values of narrower streams widened, wider ones clamped */
 } trpx_dtype;
 
 /* Device status block written by the kernels (u32 words); zeroed by each call's first node. */

@@ -104,7 +104,7 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_UNSUPPORTED and b"block" in L.trpx_last_error_string()
     rc = L.trpx_encode_indexed(2, 16, 100, 1, 7, 16, 0, 16, 16, 16, 16, 1 << 20, None)   # the decode index needs block = 12
     assert rc == _lib.ERR_UNSUPPORTED
-    rc = L.trpx_encode(9, 16, 100, 1, 12, 16, 0, 16, 16, 16, 1 << 20, None)
+    rc = L.trpx_encode(11, 16, 100, 1, 12, 16, 0, 16, 16, 16, 1 << 20, None)       # (8 / 9 are the 64-bit containers)
     assert rc == _lib.ERR_INVALID_ARG
     rc = L.trpx_decode(1, 2, 16, 10, None, 100, 1, 12, 16, 16, 16, 1 << 20, None)   # signed stream -> u16
     assert rc == _lib.ERR_UNSUPPORTED

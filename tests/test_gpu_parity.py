@@ -567,8 +567,8 @@ def test_64bit_integer_containers_are_narrowed_when_they_fit(gpu, oracle):
         assert t.is_signed() == (dt == np.int64)
         back = t.prolix_stack(np.int32 if dt == np.int64 else np.uint32)
         assert (back.astype(np.int64) == px.astype(np.int64)).all()
-    with pytest.raises(ValueError):
-        Terse(np.array([0, 1 << 40], np.int64))
+    wide = Terse(np.array([0, 1 << 40, -5, 7], np.int64))                   # wider values: 64-bit pixels (test_64bit_containers_with_wide_values)
+    assert wide.bits_per_val() == 42 and (wide.prolix(np.zeros(4, np.int64)) == [0, 1 << 40, -5, 7]).all()
 
 
 def test_more_frames_than_one_grid_slice(gpu, oracle):
@@ -870,6 +870,70 @@ def test_group_states_for_walk_free_decode_of_files(gpu, oracle, dtype, n, frame
     t2.push_back(px[0])
     assert not t2.has_group_index() and (t2.prolix(np.zeros(n, dt), frames) == px[0]).all()
     L.trpx_host_release()
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int64])
+@pytest.mark.parametrize("block", [12, 7])
+def test_64bit_containers_with_wide_values(gpu, oracle, dtype, block):
+    """Row f4: values that need more than 32 bits (what src/terse.cpp:120-123 makes of float / double images with a wide
+    range).  64-bit containers go through generic kernels with fields of up to 64 bits: stream bytes == oracle, exact round
+    trip into 64-bit containers and double, clamped into 32-bit containers (Bit_pointer.hpp:747-763), through the C ABI
+    on device memory and through both host-side Terse routes.  Inside the reference's validity domain (D3): unsigned
+    values < 2^63, |signed values| < 2^62."""
+    import torch
+    from trpx_amd import codec, _lib, Terse
+    dt = np.dtype(dtype)
+    rng = np.random.RandomState(block)
+    frames, n = 3, 1000 + block                                             # ragged last block
+    nblk = (n + block - 1) // block
+    top = 62 if dt.kind == "u" else 61
+    hi = rng.randint(0, top + 1, size=(frames, nblk))
+    hi[:, ::5] = rng.randint(33, top + 1, size=hi[:, ::5].shape)            # plenty of blocks wider than 32 bits
+    hi[1, : nblk // 2] = 0                                                  # and an empty half frame
+    mag = (rng.rand(frames, nblk * block) * 2.0 ** np.repeat(hi, block, axis=1)).astype(np.uint64)[:, :n]
+    px = mag.astype(dt)
+    if dt.kind == "i":
+        px = px * rng.choice([-1, 1], size=px.shape).astype(np.int64)
+    want, sizes, pb = oracle.encode_stack(px, block)
+    assert pb > 32
+    # device route
+    dpx = torch.from_numpy(px.view(np.int64)).to(gpu).view(codec.torch_dtype(dt))
+    enc = codec.encode(dpx, block=block)
+    torch.cuda.synchronize()
+    enc.check()
+    assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb
+    assert (np.diff(enc.frame_offsets.cpu().numpy()) == sizes.astype(np.int64)).all()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt, block=block)
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0 and (back.cpu().numpy().view(dt).reshape(frames, n) == px).all()
+    nooffs, st = codec.decode(enc.stack(), None, n, frames, dt, block=block)            # frames located by the serial walk
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0 and (nooffs.cpu().numpy().view(dt).reshape(frames, n) == px).all()
+    # host routes: converting decode into double (exact below 2^53: compare with numpy's cast) and into 32 bits (clamped)
+    stack = enc.stack().cpu().numpy()
+    offs = enc.frame_offsets.cpu().numpy().astype(np.uint64)
+    for out_dt, code in ((np.float64, _lib.F64), (np.int32 if dt.kind == "i" else np.uint32, None)):
+        out = np.zeros((frames, n), out_dt)
+        _lib.check(_lib.lib().trpx_decode_host(int(dt.kind == "i"), code if code is not None else codec.dtype_code(out_dt),
+                                               stack.ctypes.data, stack.size, offs.ctypes.data, n, frames, block, out.ctypes.data, -1))
+        if out_dt is np.float64:
+            assert (out == px.astype(np.float64)).all()
+        else:
+            info = np.iinfo(out_dt)
+            assert (out == np.clip(px.astype(object), info.min, info.max).astype(out_dt)).all()
+    # the oracle decodes the GPU's stream to the same pixels
+    assert (oracle.decode(stack[: int(sizes[0])], n, dt, block=block) == px[0]).all()
+    # the class: frames pushed one by one, prolix into 64-bit containers and double
+    t = Terse(block=block)
+    for f in px:
+        t.push_back(f)
+    assert t.bits_per_val() == pb and bytes(t._data) == want.tobytes()
+    assert (t.prolix(np.zeros(n, dt), 2) == px[2]).all() and (t.prolix_stack(np.float64) == px.astype(np.float64)).all()
+    narrow = Terse(block=block)
+    narrow.push_back((px[0] % 1000).astype(dt))                             # values that fit 32 bits: narrowed, same stream as int32 pixels
+    ref32, _, pb32 = oracle.encode_stack((px[0:1] % 1000).astype(np.int32 if dt.kind == "i" else np.uint32), block)
+    assert bytes(narrow._data) == ref32.tobytes() and narrow.bits_per_val() == pb32
+    _lib.lib().trpx_host_release()
 
 
 def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):

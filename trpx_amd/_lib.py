@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRPX_LIB") or os.path.join(_HERE, "libtrpx_hip.so")   # TRPX_LIB: kernel experiments only
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_CORRUPT, ERR_NO_DEVICE, ERR_TIMEOUT = range(8)
-U8, I8, U16, I16, U32, I32, F32, F64 = range(8)
+U8, I8, U16, I16, U32, I32, F32, F64, U64, I64 = range(10)
 STATUS_WORDS = 8
 
 

@@ -13,9 +13,10 @@ from . import _lib
 from ._lib import check, lib
 
 _TORCH2DT = {torch.uint8: _lib.U8, torch.int8: _lib.I8, torch.uint16: _lib.U16, torch.int16: _lib.I16,
-             torch.uint32: _lib.U32, torch.int32: _lib.I32}
+             torch.uint32: _lib.U32, torch.int32: _lib.I32, torch.uint64: _lib.U64, torch.int64: _lib.I64}
 _NP2TORCH = {np.dtype(np.uint8): torch.uint8, np.dtype(np.int8): torch.int8, np.dtype(np.uint16): torch.uint16,
-             np.dtype(np.int16): torch.int16, np.dtype(np.uint32): torch.uint32, np.dtype(np.int32): torch.int32}
+             np.dtype(np.int16): torch.int16, np.dtype(np.uint32): torch.uint32, np.dtype(np.int32): torch.int32,
+             np.dtype(np.uint64): torch.uint64, np.dtype(np.int64): torch.int64}
 BLOCK = 12
 
 

@@ -112,10 +112,12 @@ size_t trpx_dtype_size(int dtype) {
     case TRPX_U8: case TRPX_I8: return 1;
     case TRPX_U16: case TRPX_I16: return 2;
     case TRPX_U32: case TRPX_I32: return 4;
+    case TRPX_U64: case TRPX_I64: return 8;
     }
     return 0;
 }
-int trpx_dtype_is_signed(int dtype) { return dtype >= 0 && dtype <= TRPX_I32 ? (dtype & 1) : 0; }
+int trpx_dtype_is_signed(int dtype) { return dtype >= 0 && dtype <= TRPX_I32 ? (dtype & 1) : (dtype == TRPX_I64 ? 1 : 0); }
+static bool is64(int dtype) { return dtype == TRPX_U64 || dtype == TRPX_I64; }
 
 int trpx_device_count(void) {
     int n = 0;
@@ -192,8 +194,8 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     const IdxLayout il = idx_layout(g, n_frames);
     a.idx_group_off = index ? reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off) : nullptr;
     a.idx_widths = index ? reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths) : nullptr;
-    if (block != (unsigned)trpx::kBlock) {                 // any other block size: generic (correct-first) kernels
-        if (index) return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode_indexed: the decode index needs block=12");
+    if (block != (unsigned)trpx::kBlock || is64(dtype)) {  // any other block size, 64-bit containers: generic (correct-first) kernels
+        if (index) return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode_indexed: the decode index needs block=12 and pixels of <= 32 bits");
         HIP_TRY(trpx::launch_encode_generic(dtype, a, static_cast<hipStream_t>(stream)));
         return TRPX_OK;
     }
@@ -233,6 +235,9 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
                 uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(out_dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: unknown dtype %d", out_dtype);
+    if (is64(out_dtype))                                   // 64-bit containers: the converting decoder (fields of up to 64 bits)
+        return trpx_decode_convert(stream_signed, out_dtype, terse, terse_bytes, frame_offsets, n_values, n_frames, block, pixels_out,
+                                   status, workspace, workspace_bytes, stream);
     if (block == 0 || block > kMaxBlock)
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode: block=%u (supported: 1..%u)", block, kMaxBlock);
     if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
@@ -585,7 +590,7 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
         if (rc) return rc;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
-        if (st[0] == TRPX_ERR_CORRUPT && !convert && es < 4) { convert = true; continue; }
+        if (st[0] == TRPX_ERR_CORRUPT && !convert && es <= 4) { convert = true; continue; }   // (32-bit containers: a stream of 64-bit pixels)
         break;
     }
     if (st[0]) return fail((int)st[0], "trpx_decode_host: corrupt or truncated stream (device status %u)", st[0]);
@@ -598,7 +603,7 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_frame_offsets_host: no HIP device");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     trpx::FrameGeom g;
-    if (!terse || !terse_bytes || !frame_offsets || !n_frames || max_bits == 0 || max_bits > 32)
+    if (!terse || !terse_bytes || !frame_offsets || !n_frames || max_bits == 0 || max_bits > 64)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_frame_offsets_host: bad argument");
     if (!geom_of(n_values, block, &g))
         return fail(block != 12 ? TRPX_ERR_UNSUPPORTED : TRPX_ERR_INVALID_ARG,
@@ -831,7 +836,7 @@ int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out
                                                  count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), s->d_ws, s->ws_bytes, nullptr);
             if (rc) return rc;
             HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
-            if (st[0] == TRPX_ERR_CORRUPT && !convert && es < 4) { convert = true; continue; }
+            if (st[0] == TRPX_ERR_CORRUPT && !convert && es <= 4) { convert = true; continue; }   // (32-bit containers: a stream of 64-bit pixels)
             break;
         }
         if (st[0]) return fail((int)st[0], "trpx_stack_read: corrupt or truncated stream (device status %u)", st[0]);

@@ -30,6 +30,9 @@ template <> struct PixelTraits<uint16_t> { using U = uint16_t; static constexpr 
 template <> struct PixelTraits<int16_t>  { using U = uint16_t; static constexpr int bits = 16; static constexpr bool is_signed = true;  };
 template <> struct PixelTraits<uint32_t> { using U = uint32_t; static constexpr int bits = 32; static constexpr bool is_signed = false; };
 template <> struct PixelTraits<int32_t>  { using U = uint32_t; static constexpr int bits = 32; static constexpr bool is_signed = true;  };
+// 64-bit containers (what src/terse.cpp:120-123 makes of float / double images): generic correct-first kernels only
+template <> struct PixelTraits<uint64_t> { using U = uint64_t; static constexpr int bits = 64; static constexpr bool is_signed = false; };
+template <> struct PixelTraits<int64_t>  { using U = uint64_t; static constexpr int bits = 64; static constexpr bool is_signed = true;  };
 
 // Worst-case bits of one block: 12-bit header + 12 full-width values.
 template <typename T> constexpr int max_block_bits() { return 12 + kBlock * PixelTraits<T>::bits; }
@@ -58,6 +61,25 @@ __device__ __forceinline__ uint32_t width_from_or(uint32_t m) {
         return w > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w;  // outside D3's domain
     }
     return bl;
+}
+
+// The same for 64-bit containers (generic kernels): OR-magnitude as 64 bits.
+template <typename T>
+__device__ __forceinline__ uint32_t width_from_or64(uint64_t m) {
+    const uint32_t bl = m ? 64u - (uint32_t)__builtin_clzll(m) : 0u;
+    if (PixelTraits<T>::is_signed) {
+        const uint32_t w = m ? bl + 1u : 0u;
+        return w > (uint32_t)PixelTraits<T>::bits ? (uint32_t)PixelTraits<T>::bits : w;  // outside D3's domain
+    }
+    return bl;
+}
+template <typename T>
+__device__ __forceinline__ uint64_t magnitude64(T v) {
+    if (PixelTraits<T>::is_signed) {
+        const int64_t s = (int64_t)v;
+        return s < 0 ? (uint64_t)0 - (uint64_t)s : (uint64_t)s;       // |v| (Terse.hpp:514)
+    }
+    return (uint64_t)(typename PixelTraits<T>::U)v;
 }
 
 template <typename T>

@@ -333,13 +333,20 @@ hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipS
 // integral type (Bit_pointer.hpp:747-763) or exactly into float / double (Terse.hpp:379-383, Bit_range::next
 // :580-587).  Correct value semantics also for an unsigned stream into a signed type (reference defect D4).
 // ---------------------------------------------------------------------------------------------
+// `u`: the field zero-extended to 64 bits; `v`: the same sign-extended from its width (signed streams).
 template <typename OutT>
-__device__ __forceinline__ OutT convert_clamped(int64_t v) {
-    if constexpr (std::is_floating_point<OutT>::value) return (OutT)v;
-    else {
+__device__ __forceinline__ OutT convert_clamped(uint64_t u, int64_t v, bool stream_signed) {
+    if constexpr (std::is_floating_point<OutT>::value) return stream_signed ? (OutT)v : (OutT)u;
+    else if constexpr (sizeof(OutT) == 8) {
+        if constexpr (std::is_signed<OutT>::value)                       // int64 out: an unsigned value >= 2^63 clamps
+            return stream_signed ? (OutT)v : (u > (uint64_t)INT64_MAX ? (OutT)INT64_MAX : (OutT)u);
+        else                                                             // uint64 out: negative values clamp to 0
+            return stream_signed ? (v < 0 ? (OutT)0 : (OutT)v) : (OutT)u;
+    } else {
         constexpr int64_t lo = std::is_signed<OutT>::value ? -(int64_t(1) << (8 * sizeof(OutT) - 1)) : 0;
         constexpr int64_t hi = std::is_signed<OutT>::value ? (int64_t(1) << (8 * sizeof(OutT) - 1)) - 1
                                                            : (int64_t(1) << (8 * sizeof(OutT))) - 1;
+        if (!stream_signed) return (OutT)(u > (uint64_t)hi ? hi : (int64_t)u);
         return (OutT)(v < lo ? lo : (v > hi ? hi : v));
     }
 }
@@ -373,16 +380,20 @@ __global__ __launch_bounds__(kThreads) void k_unpack_conv(const uint8_t* __restr
     const uint64_t pos = tile_off[tile] + excl + hl;
     OutT* dst = pixels_out + (uint64_t)frame * g.n_values + (uint64_t)b * g.block;
     if (w == 0) { for (uint32_t k = 0; k < nb; ++k) dst[k] = (OutT)0; return; }
-    if (pos + (uint64_t)nb * w > 8 * (fe - fo) || w > 32u) { atomicMax(&status[0], 5u); return; }
+    if (pos + (uint64_t)nb * w > 8 * (fe - fo) || w > 64u) { atomicMax(&status[0], 5u); return; }
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(terse);
     const uint64_t n_dw = (terse_bytes + 3) / 4;
-    const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+    const uint64_t mask = w >= 64u ? ~0ull : ((1ull << w) - 1ull);
     uint64_t abit = 8 * fo + pos;
-    for (uint32_t k = 0; k < nb; ++k, abit += w) {
-        const uint64_t two = (uint64_t)ld_stream_dw(s32, abit >> 5, n_dw) | ((uint64_t)ld_stream_dw(s32, (abit >> 5) + 1, n_dw) << 32);
-        const uint32_t u = (uint32_t)(two >> (abit & 31)) & mask;
-        const int64_t v = stream_signed ? (int64_t)((int32_t)(u << (32u - w)) >> (32u - w)) : (int64_t)u;
-        dst[k] = convert_clamped<OutT>(v);
+    for (uint32_t k = 0; k < nb; ++k, abit += w) {                       // fields of up to 64 bits: three dwords
+        const uint64_t di = abit >> 5;
+        const uint32_t sh = (uint32_t)(abit & 31);
+        const uint64_t two = (uint64_t)ld_stream_dw(s32, di, n_dw) | ((uint64_t)ld_stream_dw(s32, di + 1, n_dw) << 32);
+        uint64_t u = two >> sh;
+        if (sh && w > 64u - sh) u |= (uint64_t)ld_stream_dw(s32, di + 2, n_dw) << (64u - sh);
+        u &= mask;
+        const int64_t v = w >= 64u ? (int64_t)u : (int64_t)(u << (64u - w)) >> (64u - w);   // sign extension (Bit_pointer.hpp:784-789)
+        dst[k] = convert_clamped<OutT>(u, v, stream_signed != 0);
     }
 }
 
@@ -392,10 +403,10 @@ static hipError_t launch_decode_convert_t(const DecodeArgs& a, int stream_signed
     zero_status(a.status, st);
     const uint64_t* offs = a.frame_offsets;
     if (have_offsets) {
-        hipLaunchKernelGGL(k_walk, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, offs, g, 32u,
+        hipLaunchKernelGGL(k_walk, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, offs, g, 64u,
                            a.widths, a.tile_off, a.status);
     } else {
-        hipLaunchKernelGGL(k_walk_serial, dim3(1), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.n_frames, g, 32u,
+        hipLaunchKernelGGL(k_walk_serial, dim3(1), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.n_frames, g, 64u,
                            a.widths, a.tile_off, a.walk_offsets, a.status);
         offs = a.walk_offsets;
     }
@@ -405,7 +416,7 @@ static hipError_t launch_decode_convert_t(const DecodeArgs& a, int stream_signed
     return hipGetLastError();
 }
 
-// dtype: 0..5 = the integral pixel types, 6 = float, 7 = double
+// dtype: 0..5 = the 8/16/32-bit integral pixel types, 6 = float, 7 = double, 8 / 9 = uint64 / int64
 hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st) {
     switch (dtype) {
     case 0: return launch_decode_convert_t<uint8_t>(a, stream_signed, have_offsets, st);
@@ -416,6 +427,8 @@ hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_sign
     case 5: return launch_decode_convert_t<int32_t>(a, stream_signed, have_offsets, st);
     case 6: return launch_decode_convert_t<float>(a, stream_signed, have_offsets, st);
     case 7: return launch_decode_convert_t<double>(a, stream_signed, have_offsets, st);
+    case 8: return launch_decode_convert_t<uint64_t>(a, stream_signed, have_offsets, st);
+    case 9: return launch_decode_convert_t<int64_t>(a, stream_signed, have_offsets, st);
     }
     return hipErrorInvalidValue;
 }

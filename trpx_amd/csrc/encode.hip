@@ -361,9 +361,15 @@ static hipError_t launch_encode_t(const EncodeArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ uint32_t block_width_g(const T* __restrict__ frame, uint64_t first, uint32_t nb) {
-    uint32_t m = 0;
-    for (uint32_t k = 0; k < nb; ++k) m |= magnitude<T>(frame[first + k]);      // OR-scan (Terse.hpp:508-514)
-    return width_from_or<T>(m);
+    if constexpr (sizeof(T) == 8) {
+        uint64_t m = 0;
+        for (uint32_t k = 0; k < nb; ++k) m |= magnitude64<T>(frame[first + k]);
+        return width_from_or64<T>(m);
+    } else {
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < nb; ++k) m |= magnitude<T>(frame[first + k]);  // OR-scan (Terse.hpp:508-514)
+        return width_from_or<T>(m);
+    }
 }
 
 // width of block b and of the block before it (0 at the start of a frame); one __syncthreads()
@@ -447,9 +453,18 @@ __global__ __launch_bounds__(kThreads) void k_pack_g(const T* __restrict__ pixel
     or_bits_g(out32, abit, header_val(w, w_prev), hl);
     abit += hl;
     if (w) {
-        const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
         const uint64_t first = (uint64_t)(t * kTileBlocks + threadIdx.x) * g.block;
-        for (uint32_t k = 0; k < nb; ++k, abit += w) or_bits_g(out32, abit, (uint32_t)fp[first + k] & mask, w);   // Bit_pointer.hpp:707-711
+        if constexpr (sizeof(T) == 8) {                       // fields of up to 64 bits: low and high half
+            const uint64_t mask = w >= 64u ? ~0ull : ((1ull << w) - 1ull);
+            for (uint32_t k = 0; k < nb; ++k, abit += w) {
+                const uint64_t v = (uint64_t)fp[first + k] & mask;
+                or_bits_g(out32, abit, (uint32_t)v, w < 32u ? w : 32u);
+                if (w > 32u) or_bits_g(out32, abit + 32u, (uint32_t)(v >> 32), w - 32u);
+            }
+        } else {
+            const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
+            for (uint32_t k = 0; k < nb; ++k, abit += w) or_bits_g(out32, abit, (uint32_t)fp[first + k] & mask, w);   // Bit_pointer.hpp:707-711
+        }
     }
 }
 
@@ -478,6 +493,8 @@ hipError_t launch_encode_generic(int dtype, const EncodeArgs& a, hipStream_t st)
     case 3: return launch_encode_generic_t<int16_t>(a, st);
     case 4: return launch_encode_generic_t<uint32_t>(a, st);
     case 5: return launch_encode_generic_t<int32_t>(a, st);
+    case 8: return launch_encode_generic_t<uint64_t>(a, st);
+    case 9: return launch_encode_generic_t<int64_t>(a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -39,7 +39,9 @@ namespace trpx {
 // 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms; 4096^2 i32:
 // 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
 template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
-template <typename T> constexpr int fused_occupancy() { return sizeof(T) <= 2 ? 7 : 4; }   // workgroups per CU (LDS image + VGPR budget)
+// workgroups per CU (LDS image + VGPR budget).  16-bit pixels at eight: 64 VGPRs with 4 spilled, 0.281 instead of 0.270 ms;
+// 8-bit pixels at eight: 0.272 instead of 0.292 ms per noisy 2000-frame stack
+template <typename T> constexpr int fused_occupancy() { return sizeof(T) == 1 ? 8 : (sizeof(T) == 2 ? 7 : 4); }   // workgroups per CU (LDS image + VGPR budget)
 // Every wait on another tile is bounded in WALL time: a poll loop gives up kWaitTicks of the 100 MHz realtime counter
 // after it started (0.25 s; the whole 2000-frame launch takes 0.3 ms, so this only ever triggers when tiles do not
 // make progress at all), checked every 64 polls.  The caller then sees TRPX_ERR_TIMEOUT in status[0]

@@ -23,7 +23,8 @@ from . import _lib
 from ._lib import check, lib
 
 _NP2DT = {np.dtype(np.uint8): _lib.U8, np.dtype(np.int8): _lib.I8, np.dtype(np.uint16): _lib.U16,
-          np.dtype(np.int16): _lib.I16, np.dtype(np.uint32): _lib.U32, np.dtype(np.int32): _lib.I32}
+          np.dtype(np.int16): _lib.I16, np.dtype(np.uint32): _lib.U32, np.dtype(np.int32): _lib.I32,
+          np.dtype(np.uint64): _lib.U64, np.dtype(np.int64): _lib.I64}
 
 
 _NP2DT_OUT = dict(_NP2DT)
@@ -34,7 +35,7 @@ def _code(dt, decode: bool = False) -> int:
     try:
         return (_NP2DT_OUT if decode else _NP2DT)[np.dtype(dt)]
     except KeyError:
-        raise TypeError(f"Terse: unsupported pixel type {dt} (encode: u8/i8/u16/i16/u32/i32; decode also "
+        raise TypeError(f"Terse: unsupported pixel type {dt} (encode: u8/i8/u16/i16/u32/i32/u64/i64; decode also "
                         f"float32/float64)") from None
 
 
@@ -71,12 +72,11 @@ class Terse:
         a = a.reshape(a.shape[0], -1)
         if a.dtype in (np.dtype(np.int64), np.dtype(np.uint64)):
             # 64-bit integers (what src/terse.cpp:120-123 makes of float images): values that fit 32 bits give the same
-            # stream whatever the container type, so they are narrowed here; wider ones are refused (no 64-bit fields on
-            # the device path)
+            # stream whatever the container type, so they are narrowed here and take the tuned kernels; a stack with wider
+            # values goes through as 64-bit pixels (generic kernels, fields of up to 64 bits)
             narrow = np.int32 if a.dtype.kind == "i" else np.uint32
-            if a.size and (a.min() < np.iinfo(narrow).min or a.max() > np.iinfo(narrow).max):
-                raise ValueError("a 64-bit value needs more than 32 bits (not supported on the GPU path)")
-            a = a.astype(narrow)
+            if not (a.size and (a.min() < np.iinfo(narrow).min or a.max() > np.iinfo(narrow).max)):
+                a = a.astype(narrow)
         code = _code(a.dtype)
         n_frames, n = a.shape
         if n_frames == 0:
