@@ -4,8 +4,8 @@
 // every argument with a .tif / .tiff / .TIF / .TIFF extension is read, all images of its stack are pushed into ONE
 // Terse object (one device call for the whole stack) and written next to it as <name>.trpx; -verbose prints the
 // reference's report.  Differences: the input is kept unless -delete is given (the reference always deletes it,
-// terse.cpp:82); float / double TIFFs are converted to 64-bit integers like the reference does (:120-123) and encoded
-// when every value fits 32 bits -- the device path has no 64-bit fields.
+// terse.cpp:82); float / double TIFFs are converted to 64-bit integers like the reference does (:120-123): values that all
+// fit 32 bits take the tuned kernels (the stream is the same), wider ones the generic 64-bit kernels.
 #include <chrono>
 #include <cmath>
 #include <cstring>
