@@ -936,6 +936,38 @@ def test_64bit_containers_with_wide_values(gpu, oracle, dtype, block):
     _lib.lib().trpx_host_release()
 
 
+def test_large_frames_in_a_long_stack_take_the_tiled_path(gpu, oracle):
+    """The per-frame decoder packs a block's bit position and width into 32 bits (frames of < 2^26 bits worst case).  A
+    stack of >= 128 frames whose worst case is larger (1500 x 1500 int32: 74 Mbit) must be routed to the tiled kernels --
+    also when the per-frame path is forced -- and decode exactly."""
+    import torch
+    from trpx_amd import codec
+    frames, n = 130, 1500 * 1500
+    px = codec.synth(np.int32, 5, frames, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    for f in (0, 64, 129):
+        want, pb = oracle.encode(px[f].cpu().numpy())
+        o = enc.frame_offsets.cpu().numpy()
+        assert enc.stack()[int(o[f]): int(o[f + 1])].cpu().numpy().tobytes() == want.tobytes()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.int32)
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0 and torch.equal(back, px)
+    script = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from trpx_amd import codec\n"
+        "px = codec.synth(np.int32, 5, 130, 1500 * 1500)\n"
+        "enc = codec.encode(px); torch.cuda.synchronize(); enc.check()\n"
+        "back, st = codec.decode(enc.stack(), enc.frame_offsets, 1500 * 1500, 130, np.int32); torch.cuda.synchronize()\n"
+        "assert int(st[0].item()) == 0 and torch.equal(back, px)\n"
+        "print('OK')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([os.sys.executable, "-c", script], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TRPX_DECODE_PATH="frames"))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):
     """configs[4] (16 000 frames 512x512 u16, GPU g <- frames [2000 g, 2000 g + 2000)) on the one GPU of the test box:
     the eight shards are encoded one after the other exactly as eight ranks would (same frame numbers, same calls), their
