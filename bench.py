@@ -6,8 +6,8 @@ A "step" = one pass of the hot path over one batch: Terse-encode the resident 20
 (RCCL, N>1 only), Prolix-decode it again (configs[2]).  Inputs are resident in HBM before the timed
 region; nothing is cached between steps (outputs are re-produced every step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N ranks, one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same, under a launcher)
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed on the launch stream) and `cpu_baseline` (the reference's CPU path, N=1 only).
@@ -93,6 +93,54 @@ def cpu_baseline(px_host: np.ndarray, cores: int):
     }
 
 
+def rank_commands(n: int, port: int):
+    """One (argv, env additions) pair per rank: this script again, with the rendezvous a launcher would have set."""
+    argv = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn-dry-run"]
+    return [(argv, {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}) for r in range(n)]
+
+
+def spawn_ranks(n: int, dry_run: bool) -> int:
+    """`python bench.py --gpus N` started without torch.distributed.run: start the N ranks as child processes (one per
+    GPU; frames are independent, Terse.hpp:502-505, so every rank codes its own 2000-frame shard), relay rank 0's JSON
+    line and return the worst exit code.  This parent never initialises the GPU and nothing is exec'd after GPU init."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                      # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmds = rank_commands(n, port)
+    if dry_run:
+        for argv, env in cmds:
+            print(json.dumps({"argv": argv, "env": env}))
+        return 0
+    procs = []
+    for r, (argv, env) in enumerate(cmds):
+        procs.append(subprocess.Popen(argv, env={**os.environ, **env}, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    worst, pending = 0, set(range(n))
+    out0 = b""
+    while pending:
+        for r in sorted(pending):
+            p = procs[r]
+            try:
+                if r == 0:
+                    o, _ = p.communicate(timeout=0.5)
+                    out0 += o or b""
+                else:
+                    p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if p.returncode != 0:
+                worst = worst or (p.returncode if p.returncode > 0 else 1)
+                for q in pending:                   # a rank that died would leave the others in the barrier: end them (exact PIDs)
+                    procs[q].terminate()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,17 +148,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default: configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spawn-dry-run", action="store_true",
+                    help="print the per-rank command lines / environments `--gpus N` would start, and exit (no GPU call)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the informative legs (configs[3], noisy_u16, index decode): profiler passes see the headline kernels only")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: this process becomes the launcher (it never touches the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, args.spawn_dry_run))
+    if args.spawn_dry_run:
+        sys.exit(spawn_ranks(args.gpus, True))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launcher and flag disagree)")
+    if "TRPX_BENCH_SPAWN_SELFTEST" in os.environ:       # tests/test_sharded.py: the launcher's relay / exit-code logic, no GPU
+        if os.environ["TRPX_BENCH_SPAWN_SELFTEST"] == f"fail:{rank}":
+            sys.exit(3)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "master": os.environ["MASTER_ADDR"]}))
+        sys.exit(0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # TRPX_BENCH_FORCE_DIST=1: run the RCCL code path (init, size gather, barrier) even with one rank (self test)

@@ -91,3 +91,36 @@ def test_frame_range_partitions_exactly():
             assert r[0][0] == 0 and r[-1][1] == total
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
     assert sharded.frame_range(16000, 3, 8) == (6000, 8000)
+
+
+def _bench(*args, env=None):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` (no launcher) becomes the launcher: one child per GPU with the rendezvous in its environment."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "3", "--spawn-dry-run")
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 2
+    for rank, ln in enumerate(lines):
+        assert ln["argv"][1].endswith("bench.py") and ln["argv"][2:] == ["--gpus", "2", "--steps", "3"]
+        assert ln["env"]["RANK"] == ln["env"]["LOCAL_RANK"] == str(rank)
+        assert ln["env"]["WORLD_SIZE"] == "2" and ln["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert lines[0]["env"]["MASTER_PORT"] == lines[1]["env"]["MASTER_PORT"]
+
+
+def test_bench_launcher_relays_rank0_line_and_worst_exit_code():
+    import json
+    ok = _bench("--gpus", "3", env={"TRPX_BENCH_SPAWN_SELFTEST": "1"})
+    assert ok.returncode == 0, ok.stderr
+    lines = [x for x in ok.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"selftest": True, "n_gpus": 3, "master": "127.0.0.1"}
+    bad = _bench("--gpus", "3", env={"TRPX_BENCH_SPAWN_SELFTEST": "fail:2"})
+    assert bad.returncode == 3
+    mismatch = _bench("--gpus", "2", env={"WORLD_SIZE": "4", "RANK": "0", "TRPX_BENCH_SPAWN_SELFTEST": "1"})
+    assert mismatch.returncode != 0 and "disagree" in mismatch.stderr
