@@ -5,7 +5,7 @@ import numpy as np, torch
 from trpx_amd import codec, _lib
 L = _lib.lib()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-n = 512 * 512
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 512 * 512
 px = codec.synth(np.uint16, 0, frames, n)
 enc = codec.encode(px); torch.cuda.synchronize()
 ws = codec.Workspace("cuda")

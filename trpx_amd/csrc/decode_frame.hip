@@ -26,11 +26,14 @@
 
 namespace trpx {
 
-constexpr int kFrameWaves = 4;                          // waves per workgroup: 1 walker + 3 extraction waves
+#ifndef TRPX_FRAME_WAVES
+#define TRPX_FRAME_WAVES 4
+#endif
+constexpr int kFrameWaves = TRPX_FRAME_WAVES;           // waves per workgroup: 1 walker + the extraction waves
 constexpr int kFrameThreads = kFrameWaves * kWave;
 
 #ifndef TRPX_FRAME_CHUNK_DW
-#define TRPX_FRAME_CHUNK_DW 2048
+#define TRPX_FRAME_CHUNK_DW 1024
 #endif
 template <typename T>
 struct FrameCfg {
@@ -45,7 +48,15 @@ struct FrameCfg {
     // 0.30 ms; cold (decode after an encode, the bench's round trip): 0.40 / 0.37 / 0.35 / 0.40 ms -- the extraction waves
     // re-read the window's lines from L2, and 250 workgroups per XCD x 16 KB is all of its 4 MB
     static constexpr int kChunkDw = TRPX_FRAME_CHUNK_DW;
-    static constexpr bool kOutStaged = sizeof(T) == 4;                   // 32-bit pixels: through the wave's LDS row, 16 bytes per lane and store
+    // Pixels leave through the extraction wave's LDS row, 16 bytes per lane and store: every store instruction writes whole
+    // 128-byte lines.  (Lane-owned 24-byte runs as 16 + 8 byte stores leave every line to be merged from two instructions in
+    // L2; with 2048 frames in flight lines were written back half merged -- WRITE_SIZE 1.17 x the pixels -- and the kernel fell
+    // from 0.26 to 0.38 ms.  TRPX_DEC_DIRECT_STORES: the round-2 stores for 8/16-bit pixels, A/B only.)
+#ifdef TRPX_DEC_DIRECT_STORES
+    static constexpr bool kOutStaged = sizeof(T) == 4;
+#else
+    static constexpr bool kOutStaged = true;
+#endif
     static constexpr int kRawDw = 4 * RawQuads<T>::n;                    // stream dwords a lane loads for its block
     static constexpr int kOutDw = kWave * kBlock * (int)sizeof(T) / 4;   // an extraction wave's output row: 64 blocks of pixels
     static_assert(kChunkDw % (kWave * 4) == 0, "window = whole 1 KB pieces");
@@ -61,21 +72,29 @@ __device__ __forceinline__ void lds_dma16(const uint32_t* src, uint32_t lds_base
 }
 
 template <typename T>
-__global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
                                                                uint32_t* __restrict__ status) {
     using Cfg = FrameCfg<T>;
-    constexpr int kGroupsPerWave = Cfg::kGpw, kStepBlocks = Cfg::kStepBlocks, kChunkDw = Cfg::kChunkDw;
+    constexpr int kStepBlocks = Cfg::kStepBlocks, kChunkDw = Cfg::kChunkDw;
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kChunkDw + 4];  // walker's window of the stream
-    // per block: bit position of its first payload bit (relative to dword frame_dw, 26 bits) | width << 26 (double buffered).  [0] = the
-    // width of the block before the super-step, [1 + i] = its blocks, 64 spare entries behind (fast steps)
-    __shared__ uint32_t s_pos[2][kStepBlocks + 68];
+    // Per block b of a super-step, entry [b - first block of the super-step] = H(b): bit position of the block's HEADER
+    // (relative to dword frame_dw, 26 bits) | width of the block BEFORE it << 26; one entry more for the block behind the
+    // super-step.  H(b + 1) is all the extraction needs of block b: the block's width and the end of its payload.
+    // (Double buffered.  The walker's last step of a super-step may run up to 63 blocks over its end, and a fast step writes
+    // 64 entries: the entries behind the super-step's end are copied to the front of the other buffer when the next one starts.)
+    constexpr int kPosEntries = kStepBlocks + 64 + 68;
+    __shared__ uint32_t s_pos[2][kPosEntries];
     uint32_t* const s_posx = &s_pos[0][0];
     constexpr uint32_t kPosBits = 26, kPosMask = (1u << kPosBits) - 1u;
     __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][Cfg::kOutStaged ? Cfg::kOutDw : 4];  // a group's pixels, per extraction wave
     __shared__ uint32_t s_err;
+#ifdef TRPX_DEC_LDS_PAD
+    __shared__ uint32_t s_pad[TRPX_DEC_LDS_PAD / 4];   // diagnostic build: fewer workgroups per CU
+    if (terse_bytes == 1) s_pad[threadIdx.x] = 0;
+#endif
     __shared__ uint32_t s_role[kFrameWaves];
 
     const uint32_t lane = (uint32_t)lane_id();
@@ -117,7 +136,10 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
     // Super-steps: step 0 is short when frames can be handed over (one group per extraction wave: the decision "this
     // frame's headers are too dense for the serial walk" falls after 192 blocks instead of 768 -- a header-dense stack spends
     // 0.04 instead of 0.11 ms here before its frames go to the position-parallel walk); every later step is kStepBlocks.
-    const uint32_t sb0 = defer ? (uint32_t)((kFrameWaves - 1) * kWave) : (uint32_t)kStepBlocks;
+    // The boundaries are multiples of 64 blocks, so an extraction group's pixels are whole 128-byte lines written by one
+    // wave (groups that cut lines -- super-steps ending where the walker's last step happened to end -- cost the stores
+    // 0.25 ms per stack: partial-line writes).
+    const uint32_t sb0 = defer ? (uint32_t)((kFrameWaves - 1) * kWave) : (uint32_t)kStepBlocks;   // (a multiple of 64 either way)
     const uint32_t n_steps = n_blocks <= sb0 ? 1u : 1u + (n_blocks - sb0 + kStepBlocks - 1) / kStepBlocks;
     auto step_begin = [&](uint32_t t) -> uint32_t { return t == 0u ? 0u : sb0 + (t - 1u) * kStepBlocks; };
     T* __restrict__ fout = pixels_out + frame * g.n_values;
@@ -127,8 +149,11 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
 #endif
     // walker state (wave-uniform)
     int32_t c_lo = 0, c_hi = 0;                        // the window holds dwords [c_lo, c_hi) of the frame
-    uint32_t b = 0, w_prev = 0, pos = 0, final_pos = 0;
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);      // the walk is the critical path
+    uint32_t b = 0, w_prev = 0, pos = 0;               // next block, width of the block before it, bit position of its header in the frame
+#ifndef TRPX_DEC_WALK_PRIO
+#define TRPX_DEC_WALK_PRIO 3
+#endif
+    if (wave == 0) __builtin_amdgcn_s_setprio(TRPX_DEC_WALK_PRIO);      // the walk is the critical path
 
 #ifdef TRPX_DEC_STAMPS
     uint64_t st_work = 0, st_wait = 0, st_t0 = __builtin_readcyclecounter(), st_start = st_t0;
@@ -138,61 +163,121 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
             if (s < n_steps) {
                 const uint32_t buf = s & 1u;
                 const uint32_t beg_b = step_begin(s);
-                const uint32_t end_b = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
-                if (lane == 0) s_pos[buf][0] = w_prev << kPosBits;
+                const uint32_t end_nom = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
+                // fast steps need 64 candidate blocks none of which is the frame's last (its value count differs)
+                const int32_t fast_lim = (int32_t)end_nom < (int32_t)n_blocks - 64 ? (int32_t)end_nom : (int32_t)n_blocks - 64;
+                uint32_t* const ent = s_posx + buf * kPosEntries;                  // this super-step's entries
                 bool bad = false;
-                const uint32_t fast_end = end_b < n_blocks ? end_b : n_blocks - 1;   // the frame's last block: general step
-                while (b < end_b) {
-                    // ---- fast steps: 64 candidates inside the LDS window ----------------------------------------------------
-                    // One step = one run of equal widths + the explicit header behind it (or the super-step's last block).
-                    // The step's serial chain: position -> LDS read -> ballot -> s_ff1 -> two v_readlane -> a few scalar
-                    // adds.  Every lane decodes "its" explicit header before the ballot resolves (Terse.hpp:362-370), so the
-                    // block that ends the run only has to be picked, not parsed; the store (first payload bit | width, for the
-                    // extraction waves) is unconditional: lanes behind the step's last block write values the next step
-                    // overwrites.  One branch per step.  (Measured and dropped: consuming the block AFTER the explicit one in
-                    // the same step, 602 -> 436 steps per synth-v1 frame but each 40 % longer; a scalar block-by-block walk for
-                    // header-dense streams, 3.7 instead of 3.2 ms per noisy stack; decoding the header on the scalar unit
-                    // after the pick, 15 instead of 30 vector but 46 instead of 31 scalar instructions: no faster; a ring of
-                    // LDS slots with the next slot(s) in flight instead of this window: the walker alone 5-10 % faster, the
-                    // whole kernel 5-15 % slower)
+                if (s > 0u && lane <= b - beg_b)                                   // what the step before walked behind its end, H(b) included
+                    ent[lane] = s_posx[(buf ^ 1u) * kPosEntries + (beg_b - step_begin(s - 1u)) + lane];
+                while (true) {
+                    // ---- fast steps: 64 candidate headers inside the LDS window ------------------------------------------------
+                    // One step = one run of blocks that repeat the width before them (header bit 1, Terse.hpp:361) + the
+                    // explicit header that ends it.  A single wave issues an instruction every ~4-5 cycles whatever the
+                    // dependencies, and eight walkers share a CU's scalar unit, so the step is built for the smallest
+                    // instruction COUNT: every lane tests one candidate at stride 1 + 12 w and stores H (header position |
+                    // previous width) for it unconditionally -- entries behind the step's last block are overwritten by the
+                    // next step --; the header that ends the run is parsed on the scalar unit after the pick, widths < 7 (one
+                    // 3-bit field) on the straight path (Terse.hpp:362-370); runs of 64 take a second, shorter path.  The
+                    // state lives in SGPRs.  (Round 2's step parsed every lane's header before the ballot and wrote payload
+                    // positions: 27 vector + 43 scalar instructions against 12 + 21 here.)
                     {
+                        // (hand-scheduled: hipcc's structurizer spends ~25 copies and flag materialisations per step on this loop)
+                        const uint32_t base8 = 8u * (uint32_t)(uintptr_t)&s_chunk[0];         // the window's LDS address, in bits (a multiple of 128)
+                        uint32_t pw = frame_sh + pos - 32u * (uint32_t)c_lo + base8;          // the header's bit address in LDS
                         uint32_t stride = 1u + kBlock * w_prev;
-                        int32_t pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;   // window holds 64 candidates + peek
-                        uint32_t wide = 0;                                // widest explicit block of these steps (checked once, after them)
-                        const uint32_t pbase = (uint32_t)(buf * (kStepBlocks + 68)) + 1u - beg_b;             // s_pos index of block 0
-                        while (b < fast_end && (int32_t)pos < pos_max) {
-                            const uint32_t lpos = pos + __umul24(lane, stride);
-                            const uint32_t fbit = frame_sh - 32u * (uint32_t)c_lo + lpos;
-                            const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
-                            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
-                            const uint32_t wk = w3 != 7u ? w3 : (wa != 10u ? wa : wb);
-                            const uint32_t hlk = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
-                            const uint32_t advk = hlk + kBlock * wk;                                    // header + payload bits
-                            const uint64_t stop = ~__ballot((bits & 1u) != 0u);                           // Terse.hpp:361
-                            const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                            const uint32_t room = fast_end - b;                                         // the super-step's last block ends the step at the latest
-                            const uint32_t lim = room < 64u ? room : 64u;
-                            const bool run = first >= lim;                                              // all `lim` blocks repeat w_prev
-                            const uint32_t src = run ? 63u : first;
-                            const uint32_t x_w = (uint32_t)__builtin_amdgcn_readlane((int)wk, (int)src);
-                            const uint32_t x_adv = (uint32_t)__builtin_amdgcn_readlane((int)advk, (int)src);
-                            const uint32_t e_w = run ? w_prev : x_w;
-                            wide = e_w > wide ? e_w : wide;
-                            s_posx[pbase + b + lane] = frame_sh + lpos + (lane < first ? 1u + (w_prev << kPosBits) : hlk + (wk << kPosBits));
-                            pos += run ? lim * stride : first * stride + x_adv;                         // (bounded by pos_max: inside the window)
-                            b += run ? lim : first + 1u;
-                            w_prev = e_w;
-                            stride = 1u + kBlock * e_w;
-                            pos_max = 32 * (c_hi - 1) - (int32_t)frame_sh - 63 * (int32_t)stride;
-                        }
-                        if (wide > kMaxW) bad = true;                     // a corrupt header: at worst the steps above wrote bogus widths to LDS
-                        if (bad || b >= end_b) break;
+                        const uint32_t pw_end = 32u * (uint32_t)(c_hi - c_lo - 1) + base8;    // (signed compares below: c_hi == c_lo before the first refill)
+                        uint32_t pw_max = pw_end - 63u * stride;                              // 64 candidates + one dword inside the window
+                        uint32_t v_ls = __umul24(lane, stride);
+                        const uint32_t e_base = 32u * (uint32_t)c_lo - base8;                 // LDS bit address -> position relative to dword frame_dw
+                        uint32_t s_e = e_base + (w_prev << kPosBits);
+                        const uint32_t v_entl = (uint32_t)(uintptr_t)ent - 4u * beg_b + 4u * lane;   // LDS address of this lane's entry for b = 0
+                        uint32_t s_bad = 0, t_first, t_h, t_t, t_p, t_a, t_bits;
+                        asm volatile(
+                            "s_cmp_lt_i32 %[b], %[lim]\n\t"
+                            "s_cbranch_scc0 9f\n\t"
+                            "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"
+                            "s_cbranch_scc0 9f\n"
+                            "1:\n\t"
+                            "v_add_u32 %[p], %[pw], %[ls]\n\t"                 // this lane's candidate header
+                            "v_lshrrev_b32 %[a], 3, %[p]\n\t"
+                            "v_and_b32 %[a], 0x1ffffffc, %[a]\n\t"
+                            "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"
+                            "v_add_u32 %[bits], %[se], %[p]\n\t"              // H = header position | previous width
+                            "v_lshl_add_u32 %[a], %[b], 2, %[entl]\n\t"
+                            "ds_write_b32 %[a], %[bits]\n\t"
+                            "s_waitcnt lgkmcnt(1)\n\t"
+                            "v_alignbit_b32 %[bits], v63, v62, %[p]\n\t"
+                            "v_and_b32 %[a], 1, %[bits]\n\t"
+                            "v_cmp_eq_u32 vcc, 0, %[a]\n\t"                   // lanes whose block has an explicit header (Terse.hpp:361)
+                            "s_cbranch_vccz 5f\n\t"
+                            "s_ff1_i32_b64 %[first], vcc\n\t"
+                            "v_readlane_b32 %[h], %[bits], %[first]\n\t"
+                            "s_bfe_u32 %[w], %[h], 0x30001\n\t"               // Terse.hpp:362
+                            "s_cmp_lg_u32 %[w], 7\n\t"
+                            "s_cbranch_scc0 6f\n\t"
+                            "s_addc_u32 %[b], %[b], %[first]\n\t"             // b += first + 1 (SCC = 1)
+                            "s_mul_i32 %[t], %[first], %[stride]\n\t"
+                            "s_mul_i32 %[stride], %[w], 12\n\t"
+                            "s_add_i32 %[pw], %[pw], %[t]\n\t"
+                            "s_add_i32 %[stride], %[stride], 1\n\t"
+                            "s_add_i32 %[pw], %[pw], %[stride]\n\t"
+                            "s_add_i32 %[pw], %[pw], 3\n"                      // pos += first * stride + 4 + 12 w
+                            "3:\n\t"
+                            "v_mul_u32_u24 %[ls], %[stride], %[lane]\n\t"
+                            "s_lshl_b32 %[t], %[w], 26\n\t"
+                            "s_add_i32 %[se], %[ebase], %[t]\n\t"
+                            "s_mul_i32 %[t], %[stride], 63\n\t"
+                            "s_sub_i32 %[pwmax], %[pwend], %[t]\n"
+                            "4:\n\t"
+                            "s_cmp_lt_i32 %[b], %[lim]\n\t"
+                            "s_cbranch_scc0 9f\n\t"
+                            "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"
+                            "s_cbranch_scc1 1b\n\t"
+                            "s_branch 9f\n"
+                            "5:\n\t"                                           // 64 blocks repeat the width
+                            "s_lshl_b32 %[t], %[stride], 6\n\t"
+                            "s_add_i32 %[pw], %[pw], %[t]\n\t"
+                            "s_add_i32 %[b], %[b], 64\n\t"
+                            "s_branch 4b\n"
+                            "6:\n\t"                                           // widths >= 7: Terse.hpp:364-370
+                            "s_bfe_u32 %[t], %[h], 0x20004\n\t"
+                            "s_add_i32 %[w], %[t], 7\n\t"
+                            "s_mul_i32 %[t], %[first], %[stride]\n\t"
+                            "s_add_i32 %[pw], %[pw], %[t]\n\t"
+                            "s_add_i32 %[pw], %[pw], 6\n\t"
+                            "s_cmp_lg_u32 %[w], 10\n\t"
+                            "s_cbranch_scc1 7f\n\t"
+                            "s_bfe_u32 %[t], %[h], 0x60006\n\t"
+                            "s_add_i32 %[w], %[t], 10\n\t"
+                            "s_add_i32 %[pw], %[pw], 6\n"
+                            "7:\n\t"
+                            "s_cmp_gt_u32 %[w], %[maxw]\n\t"
+                            "s_cbranch_scc1 8f\n\t"
+                            "s_add_i32 %[b], %[b], %[first]\n\t"
+                            "s_add_i32 %[b], %[b], 1\n\t"
+                            "s_mul_i32 %[stride], %[w], 12\n\t"
+                            "s_add_i32 %[pw], %[pw], %[stride]\n\t"
+                            "s_add_i32 %[stride], %[stride], 1\n\t"
+                            "s_branch 3b\n"
+                            "8:\n\t"
+                            "s_mov_b32 %[bad], 1\n"
+                            "9:\n"
+                            : [pw] "+s"(pw), [b] "+s"(b), [w] "+s"(w_prev), [stride] "+s"(stride), [se] "+s"(s_e), [pwmax] "+s"(pw_max),
+                              [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
+                              [a] "=&v"(t_a), [bits] "=&v"(t_bits)
+                            : [lim] "s"(fast_lim), [lane] "v"(lane), [entl] "v"(v_entl), [ebase] "s"(e_base), [pwend] "s"(pw_end),
+                              [maxw] "n"(kMaxW)
+                            : "vcc", "scc", "memory", "v62", "v63");
+                        pos = pw - base8 + 32u * (uint32_t)c_lo - frame_sh;
+                        bad = s_bad != 0u;
                     }
-                    // ---- general step: refills the window; the frame's last block(s) -------------------------------------
+                    if (bad || b >= end_nom || b == n_blocks) break;                             // the super-step is complete
+                    // ---- refill the window ------------------------------------------------------------------------------------
                     const uint32_t stride = 1u + kBlock * w_prev;
                     const uint32_t need_lo = (frame_sh + pos) >> 5;
                     const uint32_t need_hi = ((frame_sh + pos + 63u * stride) >> 5) + 2;
-                    if ((int32_t)need_lo < c_lo || (int32_t)need_hi > c_hi) {       // refill the window
+                    if ((int32_t)need_lo < c_lo || (int32_t)need_hi > c_hi) {
                         c_lo = (int32_t)(((frame_dw + need_lo) & ~3ull) - frame_dw);
                         c_hi = c_lo + kChunkDw;
                         const uint64_t d0 = (uint64_t)((int64_t)frame_dw + c_lo);
@@ -215,17 +300,18 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                                 *reinterpret_cast<uint4*>(&s_chunk[i]) = x;
                             }
                         }
-                        if (b < fast_end) continue;                                   // go on with fast steps
+                        if ((int32_t)b < fast_lim) continue;                          // go on with fast steps
                     }
+                    // ---- general step: the frame's last (up to 64) blocks -------------------------------------------------------
                     const uint32_t lpos = pos + lane * stride;
                     const uint32_t fbit = frame_sh + lpos - 32u * (uint32_t)c_lo;
                     const uint32_t bits = __builtin_amdgcn_alignbit(s_chunk[(fbit >> 5) + 1], s_chunk[fbit >> 5], fbit);
-                    const uint32_t left = end_b - b;                                  // candidates inside this super-step
+                    const uint32_t left = n_blocks - b;                               // candidates left in the frame
                     const uint64_t valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
                     const uint64_t same = __ballot((bits & 1u) != 0u) & valid;        // Terse.hpp:361
                     const uint64_t stop = ~same;
                     const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                    uint32_t e_w = w_prev, new_pos, new_b, e_hl = 1;
+                    uint32_t e_w = w_prev, new_pos, new_b;
                     if (first < left && first < 64u) {                                // explicit header at block b + first
                         const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, first);
                         uint32_t w = (eb >> 1) & 7u, hl = 4;                          // Terse.hpp:362-370
@@ -235,85 +321,85 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                         }
                         if (w > kMaxW) { bad = true; break; }
                         e_w = w;
-                        e_hl = hl;
                         const uint32_t nbv = b + first + 1 == n_blocks ? nb_last : (uint32_t)kBlock;
                         new_pos = pos + first * stride + hl + nbv * w;
                         new_b = b + first + 1;
-                        if (new_b == n_blocks) final_pos = new_pos;
                     } else {                                                          // the rest of the window repeats w_prev
                         const uint32_t cnt = left < 64u ? left : 64u;
-                        if (b + cnt == n_blocks) final_pos = pos + (cnt - 1) * stride + 1u + nb_last * w_prev;
                         new_pos = pos + cnt * stride;
+                        if (b + cnt == n_blocks) new_pos = pos + (cnt - 1) * stride + 1u + nb_last * w_prev;
                         new_b = b + cnt;
                     }
-                    const uint32_t n_done = new_b - b, rel = b - beg_b;
-                    if (lane < n_done)
-                        s_pos[buf][1 + rel + lane] = frame_sh + lpos + (lane < first ? 1u + (w_prev << kPosBits) : e_hl + (e_w << kPosBits));
+                    if (lane < new_b - b) ent[b - beg_b + lane] = frame_sh + lpos + (w_prev << kPosBits);
                     pos = new_pos;
                     w_prev = e_w;
                     b = new_b;
                     if (pos > limit + 64u * 400u) { bad = true; break; }              // ran away: corrupt stream
+                    if (b == n_blocks) break;
                 }
                 if (!bad && b == n_blocks)                                            // S_f = 1 + bits/8 (Terse.hpp:547)
-                    bad = !(final_pos <= limit && 1 + (uint64_t)final_pos / 8 == fe - fo);
+                    bad = !(pos <= limit && 1 + (uint64_t)pos / 8 == fe - fo);
                 if (bad && lane == 0) s_err = 1u;
+                if (lane == 0) ent[b - beg_b] = (frame_sh + pos) | (w_prev << kPosBits);   // H(first block the walker has not seen)
                 // A stream with an explicit header every few blocks costs this walker a step per header (10 x the time of a
                 // run-dominated frame); false chains merge quickly in such streams, so the frame goes to the
                 // position-parallel walk instead (decode_seg.hip).  Decided after super-steps 0, 3 and 11 on the width
                 // changes inside the super-step just walked (9 or 12 widths per lane, outside the step loop).  (Probing the
                 // first 256 blocks instead -- a second bound in the fast loop -- hands a header-dense frame over after 0.06
                 // instead of 0.13 ms but cost every other stack 6-60 %: the loop bound became loop-variant.)
-                if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_b == step_begin(s + 1u) && end_b < n_blocks) {
-                    const uint32_t per = (end_b - beg_b) / kWave;                     // widths per lane (whole groups)
+                if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_nom == step_begin(s + 1u) && end_nom < n_blocks) {
+                    const uint32_t per = (end_nom - beg_b) / kWave;                   // widths per lane (whole groups)
                     uint32_t changes = 0;
 #pragma unroll
                     for (int i = 0; i < kStepBlocks / kWave; ++i) {
                         const uint32_t at = lane * per + i;
-                        if ((uint32_t)i < per) changes += (s_pos[buf][at] >> kPosBits) != (s_pos[buf][at + 1] >> kPosBits) ? 1u : 0u;
+                        if ((uint32_t)i < per) changes += (ent[at] >> kPosBits) != (ent[at + 1] >> kPosBits) ? 1u : 0u;
                     }
                     const uint32_t inc = wave_inclusive_scan(changes);
-                    if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > end_b - beg_b && lane == 0) s_err = 2u;
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > per * kWave && lane == 0) s_err = 2u;
                 }
             }
-#ifdef TRPX_DEC_WALK_ONLY
-        } else if (false) {                            // diagnostic build (tools): time the walker alone
-#else
         } else if (s >= 1) {
-#endif
             // The SIMD's arbiter serves equal-priority waves oldest first: with all extraction waves at priority 0 the
             // workgroups that arrived first on the CU finished after 0.17 ms, the last ones after 0.30 ms (tools/dec_stamps.py),
             // a long tail with few waves left to hide latency.  Alternating the extraction waves' priority between 0 and 1
             // from super-step to super-step, in opposite phase for odd and even wave slots, gives every workgroup the same
             // share over time: all finish within 20 % of each other, the kernel 6 % sooner.  (Three levels, rotating the
             // walkers' priority as well, or a rotation every second super-step: no better.)
+#ifndef TRPX_DEC_PRIO_FLAT
             if (((hw_slot + s) & 1u) != 0u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
             // ---- extraction of super-step s-1: this wave's groups, one after the other ----------------------------------
-            // Every lane loads the stream dwords of its own block straight from L2 (the walker has just pulled them
-            // through): dwordx4 loads starting at the dword that holds the block's first payload bit -- the walker left
-            // that position and the width in s_pos, so there is no scan here --, all kRawDw dwords whatever the widths (a
-            // 16-byte load more per lane is cheaper than a wavefront max of the widths, and the extra bytes are the
-            // neighbours').  The width-specialised bodies work on registers only and leave the packed pixels in registers;
-            // the stores follow once per group, behind all passes.  (Measured and dropped, DESIGN.md 4.3: the next group's
-            // loads issued before this group's stores -- a second register set, 64 VGPRs with spills; a group's bytes
-            // fetched into LDS by LDS-DMA and its pixels leaving through LDS rows as whole lines -- fewer, cheaper
-            // vector-memory instructions, but 60 % more scalar and LDS instructions: 0.39 instead of 0.29 ms.)
+            // One LDS read gives a lane the end of its block's payload and the block's width (H of the NEXT block).  Every
+            // lane loads the stream dwords of its own block straight from L2 (the walker has just pulled them through):
+            // dwordx4 loads starting at the dword that holds the block's first payload bit, all kRawDw dwords whatever the
+            // widths (a 16-byte load more per lane is cheaper than a wavefront max of the widths, and the extra bytes are
+            // the neighbours').  The width-specialised bodies work on registers only and leave the packed pixels in
+            // registers; the stores follow once per group, behind all passes.  (Measured and dropped, DESIGN.md 4.3: the
+            // next group's loads issued before this group's stores -- a second register set, 64 VGPRs with spills; a
+            // group's bytes fetched into LDS by LDS-DMA and its pixels leaving through LDS rows as whole lines -- fewer,
+            // cheaper vector-memory instructions, but 60 % more scalar and LDS instructions: 0.39 instead of 0.29 ms.)
             const uint32_t pbuf = (s - 1) & 1u;
             constexpr int kRawDw = Cfg::kRawDw;
             const uint32_t* __restrict__ fbase = s32 + frame_dw;          // wave-uniform base; per-lane 32-bit dword offsets
             const uint32_t step0 = step_begin(s - 1u);
-            const uint32_t gpw = (step_begin(s) - step0) / (uint32_t)((kFrameWaves - 1) * kWave);   // groups per wave in this super-step: 1 or kGroupsPerWave
-            const uint32_t g0 = (uint32_t)(wave - 1) * gpw;
+            const uint32_t step1 = step_begin(s) < n_blocks ? step_begin(s) : n_blocks;
+            const uint32_t* const ent = s_posx + pbuf * kPosEntries;
+#ifdef TRPX_DEC_WALK_ONLY
+            const uint32_t gpw = 0;                                                   // diagnostic build (tools): time the walker alone
+#else
+            const uint32_t gpw = (step_begin(s) - step0) / (uint32_t)((kFrameWaves - 1) * kWave);   // groups per wave in this super-step: 1 or kGpw
+#endif
 #pragma unroll 1
             for (uint32_t gq = 0; gq < gpw; ++gq) {
-                const uint32_t gi = g0 + gq;
-                if (step0 + gi * kWave >= n_blocks) break;                            // wave-uniform: group past the frame's end
-                const uint32_t rel = gi * kWave + lane;
-                const uint32_t blk = step0 + rel;
-                uint32_t w = 0, q = frame_sh + limit;                                 // (lanes behind the frame's end: a position behind every block's)
-                if (blk < n_blocks) {
-                    const uint32_t pw = s_pos[pbuf][1 + rel];
+                const uint32_t g0 = step0 + ((uint32_t)(wave - 1) * gpw + gq) * kWave;
+                if (g0 >= step1) break;                                               // wave-uniform: group past the frame's end
+                const uint32_t blk = g0 + lane;
+                uint32_t w = 0, q = frame_sh + limit;                                 // (lanes behind the super-step's end: a position behind every block's)
+                if (blk < step1) {
+                    const uint32_t pw = ent[blk - step0 + 1u];                        // H(blk + 1)
                     w = pw >> kPosBits;
-                    q = pw & kPosMask;                                                // first payload bit, relative to dword frame_dw
+                    q = (pw & kPosMask) - (blk + 1u == n_blocks ? nb_last : (uint32_t)kBlock) * w;   // first payload bit, relative to dword frame_dw
                 }
                 const uint32_t dq = q >> 5, sq = q & 31u;
                 const uint32_t last_dw = (uint32_t)__builtin_amdgcn_readlane((int)dq, 63) + (uint32_t)kRawDw;   // lanes ascend in position
@@ -337,7 +423,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                 if (q == 0xFFFFFFFFu) fout[0] = (T)(w + raw[0]);                      // (diagnostic build: loads only)
                 continue;
 #endif
-                const bool full = blk + 1 < n_blocks || (blk + 1 == n_blocks && nb_last == (uint32_t)kBlock);
+                const bool full = blk < step1 && (blk + 1 < n_blocks || nb_last == (uint32_t)kBlock);
                 T* __restrict__ dst = fout + (uint64_t)blk * kBlock;
                 uint64_t todo = __ballot(full);
                 if (Cfg::kOutStaged && todo == ~0ull) {
@@ -359,9 +445,9 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    store_group<T>(stage, fout + (uint64_t)(step0 + gi * kWave) * kBlock);
+                    store_group<T>(stage, fout + (uint64_t)g0 * kBlock);
                     __builtin_amdgcn_wave_barrier();                                  // (the row is rewritten by the next group)
-                } else if constexpr (sizeof(T) == 4) {                                // 32-bit pixels, the frame's last group: stores inside the bodies
+                } else if constexpr (sizeof(T) == 4) {                                // 32-bit pixels, a group with fewer than 64 full blocks: stores inside the bodies
                     while (todo) {
                         const int l0 = __builtin_ctzll(todo);
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
@@ -392,7 +478,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
                     if (full) store_packed<T>(dst, o);
 #endif
                 }
-                if (blk + 1 == n_blocks && !full) {                                   // the frame's last, partial block
+                if (blk + 1 == n_blocks && blk < step1 && !full) {                    // the frame's last, partial block
                     const uint32_t mask = w >= 32u ? 0xFFFFFFFFu : ((1u << w) - 1u);
                     uint32_t p = q;
                     for (uint32_t k = 0; k < nb_last; ++k) {
@@ -412,7 +498,7 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
 #ifdef TRPX_DEC_STAMPS
         { const uint64_t t1 = __builtin_readcyclecounter(); st_work += t1 - st_t0; st_t0 = t1; }
 #endif
-        __syncthreads();                               // super-step boundary: positions of step s published, step s-1 consumed
+        __syncthreads();                               // super-step boundary: entries of step s published, step s-1 consumed
 #ifdef TRPX_DEC_STAMPS
         { const uint64_t t1 = __builtin_readcyclecounter(); st_wait += t1 - st_t0; st_t0 = t1; }
 #endif
@@ -427,7 +513,10 @@ __global__ __launch_bounds__(kFrameThreads, 2048 / kFrameThreads) void k_decode_
         uint32_t* dbg = reinterpret_cast<uint32_t*>(fout) + 8 * wave;
         dbg[0] = (uint32_t)st_work; dbg[1] = (uint32_t)st_wait; dbg[2] = hwid; dbg[3] = (uint32_t)(st_t0 - st_start);
         dbg[4] = (uint32_t)(st_start & 0xFFFFFFFFu);
-        dbg[5] = dbg[6] = dbg[7] = 0;
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[5] = xcc;
+        dbg[6] = dbg[7] = 0;
     }
 #endif
 #ifdef TRPX_DEC_NO_STORE
