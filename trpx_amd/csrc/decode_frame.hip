@@ -33,14 +33,14 @@ constexpr int kFrameWaves = TRPX_FRAME_WAVES;           // waves per workgroup: 
 constexpr int kFrameThreads = kFrameWaves * kWave;
 
 #ifndef TRPX_FRAME_CHUNK_DW
-#define TRPX_FRAME_CHUNK_DW 1024
+#define TRPX_FRAME_CHUNK_DW 2048
 #endif
 template <typename T>
 struct FrameCfg {
 #ifdef TRPX_FRAME_GPW
     static constexpr int kGpw = TRPX_FRAME_GPW;
 #else
-    static constexpr int kGpw = sizeof(T) == 4 ? 4 : 6;                  // 64-block groups per extraction wave and super-step (LDS: 18 / 24 KB per workgroup)
+    static constexpr int kGpw = 4;                                       // 64-block groups per extraction wave and super-step (LDS: 20 KB per workgroup, 24.6 KB for 32-bit pixels)
 #endif
     static constexpr int kStepGroups = (kFrameWaves - 1) * kGpw;
     static constexpr int kStepBlocks = kStepGroups * kWave;              // 768 / 1152
@@ -65,10 +65,10 @@ struct FrameCfg {
 // One LDS-DMA piece: lane l's 16 bytes at `src` land at LDS byte address lds_base + 16 * l; no staging registers.  The
 // caller waits with s_waitcnt vmcnt(0) before it reads the bytes.  (An asm statement: with the builtin in the kernel's body
 // the host pass of hipcc 7.2 silently dropped the kernel's launch stubs.)
-__device__ __forceinline__ void lds_dma16(const uint32_t* src, uint32_t lds_base) {
+__device__ __forceinline__ void lds_dma16(const uint32_t* src_uniform, uint32_t lane_byte_offset, uint32_t lds_base) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_offset), "s"(src_uniform), "s"(lds_base) : "memory");
 }
 
 template <typename T>
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
                             // no staging registers
 #pragma unroll
                             for (int it = 0; it < kChunkDw / (kWave * 4); ++it)
-                                lds_dma16(s32 + d0 + it * kWave * 4 + lane * 4, (uint32_t)(uintptr_t)&s_chunk[it * kWave * 4]);
+                                lds_dma16(s32 + d0 + it * kWave * 4, lane * 16u, (uint32_t)(uintptr_t)&s_chunk[it * kWave * 4]);
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             // (Touching the window behind this one -- one dword of each of its lines by LDS-DMA into a scratch
                             // row, so that the next refill finds them in L2: 1.5 % faster right behind an encode, 16 % slower
@@ -436,11 +436,18 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
                         uint32_t wd = w0;
                         asm volatile("" : "+s"(wd));                                  // (a copy the compiler cannot equate with the lanes' own w: the dispatch on it stays scalar)
-                        const bool mine = w == w0;
+                        const uint64_t mine = __ballot(w == w0);
                         uint32_t ss = sq;
                         asm volatile("" : "+v"(ss));                                  // keep the specialised bodies out of LICM's reach
-                        if (mine) UnpackStageDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, wd, row);
-                        todo &= ~__ballot(mine);
+                        // Every lane runs the picked width's body and only the lanes of that width keep the result; the
+                        // loop has no divergent branch (the lane mask is applied inside stage_packed_masked), so its
+                        // wave-uniform branches stay plain s_cmp / s_cbranch pairs.  With `if (mine) body` the compiler
+                        // structurises the dispatch tree: a flag register and three scalar instructions more per level,
+                        // 30 per pass -- and the CU's scalar unit is this kernel's busiest.
+                        uint32_t o[PackedDwords<T>::n];
+                        UnpackRegsDispatch<T, 0, PixelTraits<T>::bits>::run(raw, ss, wd, o);
+                        stage_packed_masked<T>(row, o, mine);
+                        todo &= ~mine;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();

@@ -205,6 +205,50 @@ __device__ __forceinline__ void store_packed(T* __restrict__ dst, const uint32_t
     }
 }
 
+// A block's packed pixels -> the lane's LDS staging row (row = staging + lane * 3 * sizeof(T) dwords): see store_group.
+template <typename T>
+__device__ __forceinline__ void stage_packed(uint32_t* __restrict__ row, const uint32_t (&o)[PackedDwords<T>::n]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) reinterpret_cast<u4*>(row)[i] = u4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+    } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) reinterpret_cast<u2*>(row)[i] = u2{o[2 * i], o[2 * i + 1]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) row[i] = o[i];
+    }
+}
+
+// The same under a lane mask, without a divergent branch in the caller's control flow (one asm statement that narrows
+// EXEC around the LDS stores): with `if (mine) stage_packed(...)` in a loop the compiler structurises every wave-uniform
+// branch of that loop as well -- a flag register and three more scalar instructions per level of the width dispatch.
+// (LDS executes a wave's instructions in order: the wave's later reads of the row need no wait on these stores.)
+template <typename T>
+__device__ __forceinline__ void stage_packed_masked(uint32_t* __restrict__ row, const uint32_t (&o)[PackedDwords<T>::n], uint64_t lanes) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const uint32_t addr = (uint32_t)(uintptr_t)row;
+    uint64_t keep;
+    if constexpr (sizeof(T) == 4) {
+        const u4 a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]}, c = {o[8], o[9], o[10], o[11]};
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %5\n\tds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:16\n\t"
+                     "ds_write_b128 %1, %4 offset:32\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(addr), "v"(a), "v"(b), "v"(c), "s"(lanes) : "memory", "scc");
+    } else if constexpr (sizeof(T) == 2) {
+        const u2 a = {o[0], o[1]}, b = {o[2], o[3]}, c = {o[4], o[5]};
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %5\n\tds_write_b64 %1, %2\n\tds_write_b64 %1, %3 offset:8\n\t"
+                     "ds_write_b64 %1, %4 offset:16\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(addr), "v"(a), "v"(b), "v"(c), "s"(lanes) : "memory", "scc");
+    } else {
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %5\n\tds_write2_b32 %1, %2, %3 offset1:1\n\t"
+                     "ds_write_b32 %1, %4 offset:8\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(addr), "v"(o[0]), "v"(o[1]), "v"(o[2]), "s"(lanes) : "memory", "scc");
+    }
+}
+
 template <typename T, int LO, int HI>
 struct UnpackRegsDispatch {
     static __device__ __forceinline__ void run(const uint32_t (&raw)[4 * RawQuads<T>::n], uint32_t s, uint32_t w0, uint32_t (&o)[PackedDwords<T>::n]) {
@@ -262,18 +306,25 @@ __device__ __forceinline__ void unpack_stage_w(const uint32_t (&raw)[4 * RawQuad
     }
 }
 
-// The wavefront's staged group (64 blocks = 768 pixels, consecutive in `staging`) -> memory, 16 bytes per lane and store.
+// The wavefront's staged group (64 blocks = 768 pixels, consecutive in `staging`) -> memory.  Every store instruction is
+// executed by all 64 lanes and writes whole 128-byte lines: 3072 bytes as three 16-byte-per-lane stores, 1536 bytes as one
+// 16-byte and one 8-byte-per-lane store, 768 bytes as one 8-byte and one 4-byte-per-lane store (no lane masks, no branches).
 template <typename T>
 __device__ __forceinline__ void store_group(const uint32_t* __restrict__ staging, T* __restrict__ group_dst) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    constexpr int kQuads = kWave * kBlock * (int)sizeof(T) / 16;            // 16-byte pieces of the group: 48 / 96 / 192
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const int lane = lane_id();
-    const u4* src = reinterpret_cast<const u4*>(staging);
-    u4* dst = reinterpret_cast<u4*>(group_dst);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(group_dst);
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int i = 0; i < (kQuads + kWave - 1) / kWave; ++i) {
-        const int q = i * kWave + lane;
-        if (kQuads % kWave == 0 || q < kQuads) __builtin_nontemporal_store(src[q], dst + q);
+        for (int i = 0; i < 3; ++i)
+            __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[i * kWave + lane], reinterpret_cast<u4*>(dst) + i * kWave + lane);
+    } else if constexpr (sizeof(T) == 2) {
+        __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
+        __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging + 256)[lane], reinterpret_cast<u2*>(dst + 256) + lane);
+    } else {
+        __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging)[lane], reinterpret_cast<u2*>(dst) + lane);
+        __builtin_nontemporal_store((staging + 128)[lane], dst + 128 + lane);
     }
 }
 
