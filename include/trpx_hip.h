@@ -186,6 +186,17 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
 int trpx_set_encode_path(int path);
 
 /*
+ * Decoder selection (trpx_decode and the entry points built on it): 0 = auto (default: the per-frame decoder for stacks of
+ * >= 128 vector-aligned frames of < 2^26 bits, the position-parallel walk + tiled extraction for fewer / larger frames, the
+ * basic kernels for unaligned frames, other block sizes and missing frame offsets), 1 = always the basic kernels, 2 = the
+ * tiled route whenever its preconditions hold, 3 = the per-frame decoder whenever its preconditions hold (any number of
+ * frames).  Every route yields the same pixels (Terse.hpp:352-389); the setter exists for tests and A/B measurements.
+ * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames.
+ * These two variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
+ */
+int trpx_set_decode_path(int path);
+
+/*
  * trpx_encode_indexed + the one thing a stream-ordered call cannot do for itself: it waits for `stream`, reads the
  * status block and, if a look-back wait of the single-pass encoder gave up (TRPX_ERR_TIMEOUT: tiles wait for earlier
  * tiles of the same launch -- bounded to 0.25 s of wall time, never seen with in-order workgroup dispatch, but the

@@ -1011,3 +1011,94 @@ def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):
     assert rb.cpu().numpy().tolist() == bases[:-1].tolist()
     for r, (loc, tot) in enumerate(shards):
         assert torch.equal(go[r * per: (r + 1) * per + 1] - int(bases[r]), loc), r
+
+
+# ---- the decode route matrix: every route x every pixel type on the fuzz generator ---------------------
+_ROUTES = {"basic": 1, "tiles": 2, "frames": 3}
+
+
+def _fuzz_stack(rng, dt, kind, n, frames):
+    """tools/fuzz_paths.py's generator: width patterns that exercise runs, outliers, flips and long runs (inside D3)."""
+    top = 8 * dt.itemsize - (2 if dt.kind == "i" else (1 if dt.itemsize == 4 else 0))
+    nblk = (n + 11) // 12
+    if kind == 0:
+        hi = np.full((frames, nblk), rng.randint(0, top + 1))                                          # one width
+    elif kind == 1:
+        hi = rng.randint(0, top + 1, size=(frames, nblk))                                              # every block its own width
+    elif kind == 2:
+        hi = np.where(rng.rand(frames, nblk) < 0.02, rng.randint(0, top + 1, size=(frames, nblk)), 3 if top >= 3 else 1)   # runs + outliers
+    elif kind == 3:
+        hi = np.where(rng.rand(frames, nblk) < 0.5, 2, 3 if top >= 3 else 1)                          # flips every other block
+    else:
+        hi = np.repeat(rng.randint(0, top + 1, size=(frames, (nblk + 299) // 300)), 300, axis=1)[:, :nblk]   # long runs of changing widths
+    mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+    if kind % 2 == 0:
+        mag[:, : n // 3] = 0                                                                          # empty stretches
+    if dt.kind == "i":
+        mag = mag * rng.choice([-1, 1], size=mag.shape)
+    return mag.astype(dt)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("route", sorted(_ROUTES))
+def test_decode_route_matrix(gpu, oracle, route, dtype):
+    """Each decode route forced through trpx_set_decode_path (the basic kernels, the position-parallel walk + tiled
+    extraction, the per-frame decoder for any number of frames) must give the oracle's pixels for every pixel type:
+    Terse.hpp:352-389 has one answer whatever the route."""
+    import torch
+    from trpx_amd import codec, _lib
+    L = _lib.lib()
+    dt = np.dtype(dtype)
+    tdt = {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
+           4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
+    rng = np.random.RandomState(1000 * _ROUTES[route] + ALL_DTYPES.index(dtype))
+    cases = [(0, 4096, 3), (1, 12 * 768 + 4, 17), (2, 40000, 130), (3, 3000, 140), (4, 131072, 3), (2, 388, 129), (1, 52, 2)]
+    assert L.trpx_set_decode_path(9) != 0                                    # out of range: refused
+    try:
+        assert L.trpx_set_decode_path(_ROUTES[route]) == 0
+        for kind, n, frames in cases:
+            px = _fuzz_stack(rng, dt, kind, n, frames)
+            want, sizes, pb = oracle.encode_stack(px)
+            dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
+            enc = codec.encode(dpx)
+            torch.cuda.synchronize()
+            enc.check()
+            assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb, ("encode", route, dtype, kind, n, frames)
+            back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt)
+            torch.cuda.synchronize()
+            assert int(st[0]) == 0, (route, dtype, kind, n, frames, int(st[0]))
+            assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (route, dtype, kind, n, frames)
+    finally:
+        L.trpx_set_decode_path(0)
+
+
+@pytest.mark.parametrize("dtype,frames", [(np.uint16, 3000), (np.int32, 1537), (np.uint8, 4100)])
+def test_stacks_larger_than_one_round_of_workgroups(gpu, oracle, dtype, frames):
+    """The per-frame decoder runs one workgroup per frame, 2048 resident at a time for 8/16-bit pixels, 1536 for 32-bit:
+    stacks past one round (prolix.cpp:69-92 loops over any number of frames).  Full size, so checked through properties:
+    sizes == prefix differences, round trip pixel-identical, and a sample of frames -- the first, the last and the ones
+    around the round's edge -- byte-identical to the oracle's single-frame encodes."""
+    import torch
+    from trpx_amd import codec
+    n = 512 * 512
+    dt = np.dtype(dtype)
+    if dtype == np.uint8:                                                    # synth-v1 exists for u16 / i32: fold the u16 frames into bytes
+        px = (codec.synth(np.uint16, 0, frames, n, device=gpu).view(torch.int16) & 0xFF).to(torch.uint8)
+    else:
+        px = codec.synth(dtype, 0, frames, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    offs = enc.frame_offsets.cpu().numpy()
+    assert offs[0] == 0 and (np.diff(offs.astype(np.int64)) > 0).all() and int(offs[-1]) == enc.total_bytes()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt)
+    torch.cuda.synchronize()
+    assert int(st[0]) == 0
+    same = back.view(torch.uint8) == px.view(torch.uint8).reshape(back.view(torch.uint8).shape)
+    assert bool(same.all()), "round trip is not pixel-identical"
+    edge = 2048 if dt.itemsize < 4 else 1536
+    stream = enc.stack().cpu().numpy()
+    for f in sorted(x for x in {0, 1, edge - 1, edge, edge + 1, frames - 1} if x < frames):
+        want = oracle.encode(px[f].cpu().numpy().view(dt))[0]
+        got = stream[int(offs[f]): int(offs[f + 1])]
+        assert got.size == want.size and (got == want).all(), (dtype, f)

@@ -71,6 +71,7 @@ SYMBOLS = {
     "trpx_stack_close": (None, [_P]),
     "trpx_host_release": (None, []),
     "trpx_set_encode_path": (_I, [_I]),
+    "trpx_set_decode_path": (_I, [_I]),
     "trpx_profile_enable": (_I, [_I]),
     "trpx_profile_read": (_I, [C.POINTER(C.c_float), _I]),
     "trpx_synth_fill": (_I, [_I, _U64, _U64, _SZ, _SZ, _P, _P]),

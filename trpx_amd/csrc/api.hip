@@ -78,6 +78,14 @@ int g_encode_path = [] {
     const char* e = getenv("TRPX_ENCODE_PATH");
     return e && strcmp(e, "twopass") == 0 ? 1 : 0;
 }();
+// Decode route: 0 = auto, 1 = basic (decode.hip), 2 = tiled (position-parallel walk + k_unpack_tiles), 3 = per-frame
+// decoder for any number of frames.  Initialised from $TRPX_DECODE_PATH ("basic" / "tiles" / "frames"), changed by
+// trpx_set_decode_path().  A forced route is still subject to its preconditions (alignment, block = 12, frame size).
+int g_decode_path = [] {
+    const char* e = getenv("TRPX_DECODE_PATH");
+    if (!e) return 0;
+    return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3 : 0;
+}();
 struct IdxLayout { size_t group_off, widths, seg, total; };
 IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     IdxLayout l;
@@ -266,12 +274,14 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
     a.seg_ws = ws + w.seg;
-    static const bool no_defer = getenv("TRPX_NO_DEFER") != nullptr;          // (A/B checks: the per-frame decoder keeps every frame)
+#ifdef TRPX_DIAGNOSTICS
+    static const bool no_defer = getenv("TRPX_NO_DEFER") != nullptr;          // (diagnostic build: the per-frame decoder keeps every frame)
+#else
+    constexpr bool no_defer = false;
+#endif
     a.defer = no_defer ? nullptr : reinterpret_cast<uint32_t*>(ws + w.defer);
-    // TRPX_DECODE_PATH = basic | tiles | frames forces one of the three decode paths (A/B checks)
-    static const char* dpath = getenv("TRPX_DECODE_PATH") ? getenv("TRPX_DECODE_PATH") : "";
-    static const bool basic = strcmp(dpath, "basic") == 0;
-    static const bool force_tiles = strcmp(dpath, "tiles") == 0 || strcmp(dpath, "seg") == 0, force_frames = strcmp(dpath, "frames") == 0;
+    const int route = g_decode_path;                                          // trpx_set_decode_path / $TRPX_DECODE_PATH
+    const bool basic = route == 1, force_tiles = route == 2, force_frames = route == 3;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
     const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0 &&
                          block == (unsigned)trpx::kBlock;
@@ -433,6 +443,12 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
 int trpx_set_encode_path(int path) {
     if (path != 0 && path != 1) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_encode_path: 0 = auto, 1 = two-pass");
     g_encode_path = path;
+    return TRPX_OK;
+}
+
+int trpx_set_decode_path(int path) {
+    if (path < 0 || path > 3) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_decode_path: 0 = auto, 1 = basic, 2 = tiled, 3 = per-frame");
+    g_decode_path = path;
     return TRPX_OK;
 }
 

@@ -319,8 +319,12 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
     if (clear_status) {
         zero_status(a.status, st);
     }
-    // TRPX_WALK = lds keeps the one-wavefront-per-frame walk (A/B checks); default: the position-parallel walk
+    // the position-parallel walk; diagnostic builds: TRPX_WALK = lds keeps the one-wavefront-per-frame walk (A/B checks)
+#ifdef TRPX_DIAGNOSTICS
     static const bool lds_walk = getenv("TRPX_WALK") && strcmp(getenv("TRPX_WALK"), "lds") == 0;
+#else
+    constexpr bool lds_walk = false;
+#endif
     if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, st);
     return launch_walk_lds_only(a, max_w, nullptr, st);
 }

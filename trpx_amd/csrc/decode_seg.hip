@@ -563,7 +563,11 @@ __global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__
 // about kSegTargetBlocks blocks, i.e. enough wavefronts to fill the GPU even for a handful of frames (eight 4096 x 4096
 // frames: 8 x 228 wavefronts; measured walk time for them with targets 320 / 160 / 96 / 64 blocks: 1.17 / 1.03 / 0.87 / 1.08 ms).
 uint32_t seg_waves_per_frame(const FrameGeom& g) {
+#ifdef TRPX_DIAGNOSTICS
     static const uint64_t kSegTargetBlocks = getenv("TRPX_SEG_TARGET") ? (uint64_t)atoi(getenv("TRPX_SEG_TARGET")) : 96;
+#else
+    constexpr uint64_t kSegTargetBlocks = 96;
+#endif
     if (g.n_blocks <= 32768u) return 1;
     const uint64_t k = ((uint64_t)g.n_blocks + 32 * kSegTargetBlocks) / (64 * kSegTargetBlocks);
     return (uint32_t)(k ? k : 1);
