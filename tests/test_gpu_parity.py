@@ -519,7 +519,7 @@ def test_every_decode_path_every_dtype_block_to_block_width_changes(gpu, oracle,
     """One noisy stack per pixel type (the width changes with almost every block, including the type's full width),
     encoded by the single-pass encoder with the decode index, then decoded along every route the library has:
     per-frame decoder (>= 128 frames), tiled decoder (< 128 frames), walk-free indexed decoder, serial walk without
-    offsets -- three repetitions each (timing-dependent bugs show as run-to-run differences)."""
+    offsets."""
     import torch
     from trpx_amd import codec
     rng = np.random.RandomState(99)
@@ -540,13 +540,12 @@ def test_every_decode_path_every_dtype_block_to_block_width_changes(gpu, oracle,
         torch.cuda.synchronize()
         enc.check()
         assert enc.stack().cpu().numpy().tobytes() == want.tobytes(), (dtype, frames)
-        for rep in range(3):
-            for kind in ("offsets", "index", "walk"):
-                back, st = codec.decode(enc.stack(), None if kind == "walk" else enc.frame_offsets, n, frames, dt,
-                                        index=enc.index if kind == "index" else None)
-                torch.cuda.synchronize()
-                assert int(st[0]) == 0, (dtype, frames, kind)
-                assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, frames, kind, rep)
+        for kind in ("offsets", "index", "walk"):
+            back, st = codec.decode(enc.stack(), None if kind == "walk" else enc.frame_offsets, n, frames, dt,
+                                    index=enc.index if kind == "index" else None)
+            torch.cuda.synchronize()
+            assert int(st[0]) == 0, (dtype, frames, kind)
+            assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, frames, kind)
 
 
 def test_64bit_integer_containers_are_narrowed_when_they_fit(gpu, oracle):
@@ -1102,3 +1101,31 @@ def test_stacks_larger_than_one_round_of_workgroups(gpu, oracle, dtype, frames):
         want = oracle.encode(px[f].cpu().numpy().view(dt))[0]
         got = stream[int(offs[f]): int(offs[f + 1])]
         assert got.size == want.size and (got == want).all(), (dtype, f)
+
+
+def test_host_entry_points_from_two_threads(gpu, oracle):
+    """src/terse.cpp:63-69 / prolix.cpp:69-92 callers in two threads: the *_host entry points order their copies and kernels
+    on a private stream per calling thread and wait for that stream alone, so two threads neither serialise each other
+    through the null stream nor see each other's buffers; both get the oracle's bytes and their own pixels back."""
+    import threading
+    rng = np.random.RandomState(3)
+    stacks = [rng.poisson(2.0 + 3 * k, size=(60, 50000)).astype(np.uint16) for k in range(2)]
+    want = [oracle.encode_stack(p) for p in stacks]
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(6):
+                s, offs, pb = _host_encode(stacks[k])
+                assert s.tobytes() == want[k][0].tobytes() and pb == want[k][2]
+                assert (_host_decode(s, offs, stacks[k].shape[1], stacks[k].shape[0], np.uint16) == stacks[k]).all()
+                assert (_host_decode(s, None, stacks[k].shape[1], stacks[k].shape[0], np.uint16) == stacks[k]).all()
+        except Exception as ex:                                              # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors and not any(t.is_alive() for t in threads), errors

@@ -38,3 +38,17 @@ for rep in range(3):
     d_px.copy_(hp); ho.copy_(d_out); torch.cuda.synchronize()
     t1 = time.perf_counter()
     print(f"rep {rep}: bare copies (pixels H2D + stream D2H, pageable): {1e3 * (t1 - t0):7.1f} ms")
+# the same with PINNED caller memory: bare copies, and the host entry points called on pinned buffers
+pp = torch.empty(px.nbytes, dtype=torch.uint8).pin_memory(); pp.copy_(hp)
+po = torch.empty(total.value, dtype=torch.uint8).pin_memory()
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d_px.copy_(pp, non_blocking=True); po.copy_(d_out, non_blocking=True); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    print(f"rep {rep}: bare copies (pinned): {1e3 * (t1 - t0):7.1f} ms ({px.nbytes / (t1 - t0) / 1e9:5.1f} GB/s of pixels)")
+pout = torch.empty(cap, dtype=torch.uint8).pin_memory()
+for rep in range(3):
+    t0 = time.perf_counter()
+    _lib.check(L.trpx_encode_host(_lib.U16, pp.data_ptr(), n, frames, 12, pout.data_ptr(), cap, C.byref(total), offs.ctypes.data, C.byref(pb), -1))
+    t1 = time.perf_counter()
+    print(f"rep {rep}: encode_host on pinned caller buffers {1e3 * (t1 - t0):7.1f} ms ({px.nbytes / (t1 - t0) / 1e9:5.1f} GB/s of pixels)")

@@ -229,8 +229,8 @@ int trpx_encode_checked(int dtype, const void* pixels, size_t n_values, size_t n
                                            index, workspace, workspace_bytes, stream);
         t_force_two_pass = false;
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-        HIP_TRY(hipMemcpy(st, status, sizeof st, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // the caller's stream alone, not the device
         if (st[0] != TRPX_ERR_TIMEOUT) break;                // a look-back wait gave up: the two-pass pipeline has no waits
     }
     if (host_status) memcpy(host_status, st, sizeof st);
@@ -482,11 +482,18 @@ struct Arena {
     void* p[kSlots] = {};
     size_t cap[kSlots] = {};
     int device = -1;
-    hipError_t get(int slot, size_t n, void** out) {
+    hipStream_t stream = nullptr;                            // this thread's private, non-blocking stream: the host wrappers
+                                                             // order their copies and kernels on it and wait for IT alone
+    hipError_t on_device() {
         int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
+        const hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         if (dev != device) { release(); device = dev; }
+        return hipSuccess;
+    }
+    hipError_t get(int slot, size_t n, void** out) {
+        hipError_t e = on_device();
+        if (e != hipSuccess) return e;
         if (cap[slot] < n) {
             if (p[slot]) (void)hipFree(p[slot]);
             p[slot] = nullptr; cap[slot] = 0;
@@ -498,13 +505,28 @@ struct Arena {
         *out = p[slot];
         return hipSuccess;
     }
+    hipError_t get_stream(hipStream_t* out) {
+        hipError_t e = on_device();
+        if (e != hipSuccess) return e;
+        if (!stream && (e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        *out = stream;
+        return hipSuccess;
+    }
     void release() {
         for (int i = 0; i < kSlots; ++i) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
     }
+    ~Arena() { release(); }                                  // thread exit: the buffers go back (errors of a runtime that is already down are ignored)
 };
 Arena& arena() {
-    static thread_local Arena* a = new Arena;                // (not destroyed at thread exit: the HIP runtime may already be gone)
-    return *a;
+    static thread_local Arena a;
+    return a;
+}
+// copy on the caller's private stream and wait for that stream (never for the device)
+hipError_t copy_sync(hipStream_t hs, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, hs);
+    return e != hipSuccess ? e : hipStreamSynchronize(hs);
 }
 }  // namespace
 extern "C" {
@@ -530,33 +552,35 @@ int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_fr
                                "trpx_encode_host: unsupported sizes/block (block=%u)", block);
     struct { void* p; } d_px, d_out, d_off, d_st, d_ws;
     Arena& A = arena();
+    hipStream_t hs = nullptr;
+    HIP_TRY(A.get_stream(&hs));
     HIP_TRY(A.get(Arena::kPixels, in_bytes, &d_px.p));
     HIP_TRY(A.get(Arena::kStream, cap, &d_out.p));
     HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1), &d_off.p));
     HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
     HIP_TRY(A.get(Arena::kWorkspace, ws_bytes, &d_ws.p));
-    HIP_TRY(hipMemcpy(d_px.p, pixels, in_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(hs, d_px.p, pixels, in_bytes, hipMemcpyHostToDevice));
     int rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
-                         static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
+                         static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, hs);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(hs));
     uint32_t st[TRPX_STATUS_WORDS];
-    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     if (st[0] == TRPX_ERR_TIMEOUT && g_encode_path == 0) {   // never seen in practice; keeps the API total
         t_force_two_pass = true;                             // (this thread's next call only: other threads are not affected)
         rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
-                         static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr);
+                         static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, hs);
         t_force_two_pass = false;
         if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+        HIP_TRY(hipStreamSynchronize(hs));
+        HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     }
     if (st[0]) return fail((int)st[0], "trpx_encode_host: device status %u", st[0]);
     std::vector<uint64_t> offs(n_frames + 1);
-    HIP_TRY(hipMemcpy(offs.data(), d_off.p, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, offs.data(), d_off.p, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
     const size_t total = (size_t)offs[n_frames];
     if (total > out_capacity) return fail(TRPX_ERR_CAPACITY, "trpx_encode_host: need %zu bytes, have %zu", total, out_capacity);
-    HIP_TRY(hipMemcpy(out, d_out.p, total, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, out, d_out.p, total, hipMemcpyDeviceToHost));
     *total_bytes = total;
     if (frame_offsets) memcpy(frame_offsets, offs.data(), 8 * (n_frames + 1));
     if (prolix_bits) *prolix_bits = st[1];
@@ -580,15 +604,17 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
                                "trpx_decode_host: unsupported sizes/block (block=%u)", block);
     struct { void* p = nullptr; } d_in, d_out, d_off, d_st, d_ws;
     Arena& A = arena();
+    hipStream_t hs = nullptr;
+    HIP_TRY(A.get_stream(&hs));
     HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
     HIP_TRY(A.get(Arena::kPixels, out_bytes, &d_out.p));
     HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
     HIP_TRY(A.get(Arena::kWorkspace, ws_bytes, &d_ws.p));
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));   // the bytes behind the stream read as zero
-    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), hs));   // the bytes behind the stream read as zero
+    HIP_TRY(copy_sync(hs, d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
     if (frame_offsets) {
         HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1), &d_off.p));
-        HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(hs, d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
     }
     // Same signedness: the tuned decoders.  They report CORRUPT for a block wider than the output type, which is also
     // what a legitimately wider stream looks like (e.g. u16 data into a u8 container, Bit_pointer.hpp:747-763): those
@@ -599,18 +625,18 @@ int trpx_decode_host(int stream_signed, int out_dtype, const uint8_t* terse, siz
     for (;;) {
         const int rc = convert ? trpx_decode_convert(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes,
                                                      offs_dev, n_values, n_frames, block, d_out.p,
-                                                     static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, nullptr)
+                                                     static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, hs)
                                : trpx_decode(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, offs_dev,
                                              n_values, n_frames, block, d_out.p, static_cast<uint32_t*>(d_st.p), d_ws.p,
-                                             ws_bytes, nullptr);
+                                             ws_bytes, hs);
         if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+        HIP_TRY(hipStreamSynchronize(hs));
+        HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
         if (st[0] == TRPX_ERR_CORRUPT && !convert && es <= 4) { convert = true; continue; }   // (32-bit containers: a stream of 64-bit pixels)
         break;
     }
     if (st[0]) return fail((int)st[0], "trpx_decode_host: corrupt or truncated stream (device status %u)", st[0]);
-    HIP_TRY(hipMemcpy(pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
     return TRPX_OK;
 }
 
@@ -629,11 +655,13 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     const DecWs w = dec_ws(g, n_frames);
     struct { void* p = nullptr; } d_in, d_st, d_ws;
     Arena& A = arena();
+    hipStream_t hs = nullptr;
+    HIP_TRY(A.get_stream(&hs));
     HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
     HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
     HIP_TRY(A.get(Arena::kWorkspace, w.total, &d_ws.p));
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));
-    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), hs));
+    HIP_TRY(copy_sync(hs, d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
     trpx::DecodeArgs a{};
     a.terse = static_cast<const uint8_t*>(d_in.p);
     a.terse_bytes = terse_bytes;
@@ -647,12 +675,12 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
     a.seg_ws = ws + w.seg;
-    HIP_TRY(trpx::launch_walk_serial(a, max_bits, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(trpx::launch_walk_serial(a, max_bits, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
     uint32_t st[TRPX_STATUS_WORDS];
-    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     if (st[0]) return fail((int)st[0], "trpx_frame_offsets_host: corrupt or truncated stack");
-    HIP_TRY(hipMemcpy(frame_offsets, a.walk_offsets, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, frame_offsets, a.walk_offsets, 8 * (n_frames + 1), hipMemcpyDeviceToHost));
     return TRPX_OK;
 }
 
@@ -671,23 +699,25 @@ int trpx_group_states_host(const uint8_t* terse, size_t terse_bytes, const uint6
     const size_t ib = trpx_index_bytes(dtype, n_values, n_frames, block), ng = n_frames * (size_t)g.n_tiles;
     struct { void* p = nullptr; } d_in, d_off, d_st, d_idx;
     Arena& A = arena();
+    hipStream_t hs = nullptr;
+    HIP_TRY(A.get_stream(&hs));
     HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
     HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1) + 8 * ng, &d_off.p));
     HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
     HIP_TRY(A.get(Arena::kWorkspace, ib, &d_idx.p));
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));
-    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), hs));
+    HIP_TRY(copy_sync(hs, d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(hs, d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
     uint64_t* d_states = static_cast<uint64_t*>(d_off.p) + (n_frames + 1);
     int rc = trpx_build_index(dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, static_cast<const uint64_t*>(d_off.p), n_values,
-                              n_frames, block, d_idx.p, static_cast<uint32_t*>(d_st.p), nullptr);
+                              n_frames, block, d_idx.p, static_cast<uint32_t*>(d_st.p), hs);
     if (rc) return rc;
-    rc = trpx_index_group_states(d_idx.p, n_values, n_frames, block, d_states, nullptr);
+    rc = trpx_index_group_states(d_idx.p, n_values, n_frames, block, d_states, hs);
     if (rc) return rc;
     uint32_t st[TRPX_STATUS_WORDS];
-    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     if (st[0]) return fail((int)st[0], "trpx_group_states_host: corrupt or truncated stack (device status %u)", st[0]);
-    HIP_TRY(hipMemcpy(group_states, d_states, 8 * ng, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, group_states, d_states, 8 * ng, hipMemcpyDeviceToHost));
     return TRPX_OK;
 }
 
@@ -708,29 +738,31 @@ int trpx_decode_host_grouped(int stream_signed, int out_dtype, const uint8_t* te
     const size_t ib = trpx_index_bytes(out_dtype, n_values, n_frames, block);
     struct { void* p = nullptr; } d_in, d_out, d_off, d_st, d_idx;
     Arena& A = arena();
+    hipStream_t hs = nullptr;
+    HIP_TRY(A.get_stream(&hs));
     HIP_TRY(A.get(Arena::kStream, trpx::align_up(terse_bytes, 4) + 8, &d_in.p));
     HIP_TRY(A.get(Arena::kPixels, out_bytes, &d_out.p));
     HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1) + 8 * ng, &d_off.p));
     HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
     HIP_TRY(A.get(Arena::kWorkspace, ib, &d_idx.p));
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), nullptr));
-    HIP_TRY(hipMemcpy(d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(d_in.p) + (terse_bytes & ~size_t(3)), 0, trpx::align_up(terse_bytes, 4) + 8 - (terse_bytes & ~size_t(3)), hs));
+    HIP_TRY(copy_sync(hs, d_in.p, terse, terse_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(hs, d_off.p, frame_offsets, 8 * (n_frames + 1), hipMemcpyHostToDevice));
     uint64_t* d_states = static_cast<uint64_t*>(d_off.p) + (n_frames + 1);
-    HIP_TRY(hipMemcpy(d_states, group_states, 8 * ng, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(hs, d_states, group_states, 8 * ng, hipMemcpyHostToDevice));
     int rc = trpx_index_from_group_states(out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, static_cast<const uint64_t*>(d_off.p),
-                                          d_states, n_values, n_frames, block, d_idx.p, static_cast<uint32_t*>(d_st.p), nullptr);
+                                          d_states, n_values, n_frames, block, d_idx.p, static_cast<uint32_t*>(d_st.p), hs);
     if (rc) return rc;
     uint32_t st[TRPX_STATUS_WORDS];
-    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     if (st[0] == TRPX_ERR_CORRUPT)     // the states do not describe this stream (or the data are wider than the output type): general route
         return trpx_decode_host(stream_signed, out_dtype, terse, terse_bytes, frame_offsets, n_values, n_frames, block, pixels_out, device);
     rc = trpx_decode_indexed(stream_signed, out_dtype, static_cast<const uint8_t*>(d_in.p), terse_bytes, static_cast<const uint64_t*>(d_off.p),
-                             d_idx.p, n_values, n_frames, block, d_out.p, static_cast<uint32_t*>(d_st.p), nullptr);
+                             d_idx.p, n_values, n_frames, block, d_out.p, static_cast<uint32_t*>(d_st.p), hs);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, st, d_st.p, sizeof st, hipMemcpyDeviceToHost));
     if (st[0]) return fail((int)st[0], "trpx_decode_host_grouped: corrupt or truncated stream (device status %u)", st[0]);
-    HIP_TRY(hipMemcpy(pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, pixels_out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
     return TRPX_OK;
 }
 
@@ -778,27 +810,29 @@ int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse
     if (offs[0] != 0 || offs[n_frames] > terse_bytes) return fail(TRPX_ERR_CORRUPT, "trpx_stack_open: frame offsets do not fit the stack");
     for (size_t f = 0; f < n_frames; ++f)
         if (offs[f + 1] <= offs[f]) return fail(TRPX_ERR_CORRUPT, "trpx_stack_open: frame offsets are not increasing");
+    hipStream_t hs = nullptr;                                                  // the calling thread's private stream (see Arena)
+    HIP_TRY(arena().get_stream(&hs));
     trpx_stack* s = new trpx_stack;
-    HIP_TRY(hipGetDevice(&s->device));
+    auto bail = [&](hipError_t e, const char* what) { stack_free(s); return fail(TRPX_ERR_HIP, "trpx_stack_open: %s: %s", what, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipGetDevice(&s->device)) != hipSuccess) return bail(e, "hipGetDevice");
     s->stream_signed = stream_signed != 0;
     s->n_values = n_values; s->n_frames = n_frames; s->terse_bytes = terse_bytes; s->block = block;
     s->offs.swap(offs);
     const size_t frame_bytes = n_values * 8;                                   // widest output (double)
     s->window_frames = std::max<size_t>(1, std::min<size_t>(n_frames, (size_t(64) << 20) / frame_bytes));   // <= 64 MB of decoded frames
     s->ws_bytes = trpx_decode_workspace_bytes(TRPX_U8, n_values, s->window_frames, block);
-    auto bail = [&](hipError_t e, const char* what) { stack_free(s); return fail(TRPX_ERR_HIP, "trpx_stack_open: %s: %s", what, hipGetErrorString(e)); };
-    hipError_t e;
     if ((e = hipMalloc(&s->d_terse, trpx::align_up(terse_bytes, 4) + 8)) != hipSuccess) return bail(e, "hipMalloc(stack)");
     if ((e = hipMalloc(&s->d_offs, 8 * (n_frames + 1))) != hipSuccess) return bail(e, "hipMalloc(offsets)");
     if ((e = hipMalloc(&s->d_status, 4 * TRPX_STATUS_WORDS)) != hipSuccess) return bail(e, "hipMalloc(status)");
     if ((e = hipMalloc(&s->d_ws, s->ws_bytes ? s->ws_bytes : 256)) != hipSuccess) return bail(e, "hipMalloc(workspace)");
-    if ((e = hipMemset(s->d_terse, 0, trpx::align_up(terse_bytes, 4) + 8)) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = hipMemcpy(s->d_terse, terse, terse_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(stack)");
-    if ((e = hipMemcpy(s->d_offs, s->offs.data(), 8 * (n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(offsets)");
+    if ((e = hipMemsetAsync(s->d_terse, 0, trpx::align_up(terse_bytes, 4) + 8, hs)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = copy_sync(hs, s->d_terse, terse, terse_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(stack)");
+    if ((e = copy_sync(hs, s->d_offs, s->offs.data(), 8 * (n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(offsets)");
     if (group_states && block == (unsigned)trpx::kBlock && n_values % 4 == 0) {   // row f1: the file carried its group states
         s->groups = g.n_tiles;
         if ((e = hipMalloc(&s->d_states, 8 * n_frames * s->groups)) != hipSuccess) return bail(e, "hipMalloc(states)");
-        if ((e = hipMemcpy(s->d_states, group_states, 8 * n_frames * s->groups, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(states)");
+        if ((e = copy_sync(hs, s->d_states, group_states, 8 * n_frames * s->groups, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(states)");
         if ((e = hipMalloc(&s->d_index, trpx_index_bytes(TRPX_U8, n_values, s->window_frames, block))) != hipSuccess) return bail(e, "hipMalloc(index)");
     }
     *handle = s;
@@ -810,6 +844,8 @@ int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out
     const size_t es = out_dtype == TRPX_F32 ? 4 : out_dtype == TRPX_F64 ? 8 : trpx_dtype_size(out_dtype);
     if (!es) return fail(TRPX_ERR_INVALID_ARG, "trpx_stack_read: unknown dtype %d", out_dtype);
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t hs = nullptr;                                                  // the calling thread's private stream
+    HIP_TRY(arena().get_stream(&hs));
     if (out_dtype != s->win_dtype || frame < s->win_first || frame >= s->win_first + s->win_count) {
         // a miss: expand the window of frames that starts here (the callers of the reference walk the stack in order)
         const size_t count = std::min(s->window_frames, s->n_frames - frame);
@@ -825,7 +861,7 @@ int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out
         const uint8_t* base = static_cast<const uint8_t*>(s->d_terse) + first_byte;
         std::vector<uint64_t> rel(count + 1);
         for (size_t i = 0; i <= count; ++i) rel[i] = s->offs[frame + i] - first_byte;
-        HIP_TRY(hipMemcpy(static_cast<uint64_t*>(s->d_offs), rel.data(), 8 * (count + 1), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(hs, static_cast<uint64_t*>(s->d_offs), rel.data(), 8 * (count + 1), hipMemcpyHostToDevice));
         const size_t bytes = (size_t)rel[count];
         bool convert = !(out_dtype <= TRPX_I32 && (s->stream_signed != 0) == (trpx_dtype_is_signed(out_dtype) != 0));
         uint32_t st[TRPX_STATUS_WORDS];
@@ -833,25 +869,25 @@ int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out
         if (s->d_states && !convert) {                                         // walk-free: index from the file's group states
             int rc = trpx_index_from_group_states(out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs),
                                                   static_cast<const uint64_t*>(s->d_states) + frame * s->groups, s->n_values, count,
-                                                  s->block, s->d_index, static_cast<uint32_t*>(s->d_status), nullptr);
+                                                  s->block, s->d_index, static_cast<uint32_t*>(s->d_status), hs);
             if (rc) return rc;
-            HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(hs, st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
             if (st[0] == 0) {
                 rc = trpx_decode_indexed(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs), s->d_index,
-                                         s->n_values, count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), nullptr);
+                                         s->n_values, count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), hs);
                 if (rc) return rc;
-                HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
+                HIP_TRY(copy_sync(hs, st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
                 done = st[0] == 0;
             }                                                                  // (states that do not fit the stream: the general route decides)
         }
         for (; !done;) {                                                       // (same routing as trpx_decode_host)
             const int rc = convert ? trpx_decode_convert(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs),
                                                          s->n_values, count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status),
-                                                         s->d_ws, s->ws_bytes, nullptr)
+                                                         s->d_ws, s->ws_bytes, hs)
                                    : trpx_decode(s->stream_signed, out_dtype, base, bytes, static_cast<const uint64_t*>(s->d_offs), s->n_values,
-                                                 count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), s->d_ws, s->ws_bytes, nullptr);
+                                                 count, s->block, s->d_window, static_cast<uint32_t*>(s->d_status), s->d_ws, s->ws_bytes, hs);
             if (rc) return rc;
-            HIP_TRY(hipMemcpy(st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(hs, st, s->d_status, sizeof st, hipMemcpyDeviceToHost));
             if (st[0] == TRPX_ERR_CORRUPT && !convert && es <= 4) { convert = true; continue; }   // (32-bit containers: a stream of 64-bit pixels)
             break;
         }
@@ -859,7 +895,7 @@ int trpx_stack_read(trpx_stack* s, size_t frame, int out_dtype, void* pixels_out
         s->win_first = frame; s->win_count = count; s->win_dtype = out_dtype;
     }
     const size_t fb = s->n_values * es;
-    HIP_TRY(hipMemcpy(pixels_out, static_cast<const char*>(s->d_window) + (frame - s->win_first) * fb, fb, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs, pixels_out, static_cast<const char*>(s->d_window) + (frame - s->win_first) * fb, fb, hipMemcpyDeviceToHost));
     return TRPX_OK;
 }
 
