@@ -12,8 +12,9 @@
 //     its Release build, CMakeLists.txt:13); device/runtime failures throw std::runtime_error;
 //   * push_back(Iterator, size, n_frames) encodes a whole stack in one GPU call (the reference's
 //     per-frame push_back is O(F^2), defect D6);
-//   * pixel types: u8/i8/u16/i16/u32/i32 (src/terse.cpp:113-118); 64-bit integers are accepted when every value fits
-//     32 bits (the stream is then the same), otherwise rejected.
+//   * pixel types: u8/i8/u16/i16/u32/i32 (src/terse.cpp:113-118) on the tuned kernels; 64-bit integers (what
+//     src/terse.cpp:120-123 makes of float / double images) are narrowed when every value fits 32 bits (the stream is then
+//     the same) and go through as 64-bit pixels otherwise (generic kernels, no decode index).
 #ifndef TRPX_TERSE_HPP
 #define TRPX_TERSE_HPP
 
@@ -74,12 +75,31 @@ public:
     /// Reads a Terse object written by write() / the reference (Terse.hpp:279, :485-498).
     explicit Terse(std::ifstream& istream) { f_read(istream); }
 
-    /// Copy-constructible like the reference's class (the device-side copy of the stack is not shared); not assignable.
+    /// Copyable and movable like the reference's class (Terse.hpp:228-475 declares neither: the compiler's apply).  The
+    /// device-side copy of the stack (prolix(it, frame)) is never shared: a copy starts without one, a move takes it over.
     Terse(Terse const& o)
         : d_signed(o.d_signed), d_block(o.d_block), d_size(o.d_size), d_prolix_bits(o.d_prolix_bits), d_dim(o.d_dim),
           d_terse_data(o.d_terse_data), d_frame_sizes(o.d_frame_sizes), d_group_states(o.d_group_states) {}
-    Terse& operator=(Terse const&) = delete;
+    Terse(Terse&& o) noexcept
+        : d_signed(o.d_signed), d_block(o.d_block), d_size(o.d_size), d_prolix_bits(o.d_prolix_bits), d_dim(std::move(o.d_dim)),
+          d_terse_data(std::move(o.d_terse_data)), d_frame_sizes(std::move(o.d_frame_sizes)), d_stack(o.d_stack),
+          d_group_states(std::move(o.d_group_states)) {
+        o.d_stack = nullptr;
+    }
+    Terse& operator=(Terse const& o) {
+        if (this != &o) { Terse tmp(o); swap(tmp); }
+        return *this;
+    }
+    Terse& operator=(Terse&& o) noexcept {
+        if (this != &o) { swap(o); o.f_drop_stack(); }
+        return *this;
+    }
     ~Terse() { f_drop_stack(); }
+    void swap(Terse& o) noexcept {
+        std::swap(d_signed, o.d_signed); std::swap(d_block, o.d_block); std::swap(d_size, o.d_size);
+        std::swap(d_prolix_bits, o.d_prolix_bits); d_dim.swap(o.d_dim); d_terse_data.swap(o.d_terse_data);
+        d_frame_sizes.swap(o.d_frame_sizes); std::swap(d_stack, o.d_stack); d_group_states.swap(o.d_group_states);
+    }
 
     /// Appends one frame (Terse.hpp:290-302).
     template <typename Iterator>
@@ -181,7 +201,7 @@ public:
     /// XML-ish header + raw stack (Terse.hpp:454-474), byte-identical header text.  frame_index = true adds the
     /// frame_sizes and group_bit_offsets attributes: the reference reader ignores them, this
     /// reader then needs neither a device walk to locate the frames nor one to expand them.
-    void write(std::ostream& ostream, bool frame_index = false) {
+    void write(std::ostream& ostream, bool frame_index = false) const {
         trpx_header h{};
         h.prolix_bits = d_prolix_bits;
         h.is_signed = d_signed;
@@ -192,14 +212,17 @@ public:
         h.n_dims = (unsigned)std::min<std::size_t>(d_dim.size(), 8);
         for (unsigned i = 0; i < h.n_dims; ++i) h.dims[i] = d_dim[i];
         std::vector<std::uint64_t> sizes(d_frame_sizes.begin(), d_frame_sizes.end());
-        const std::size_t groups = frame_index ? trpx_group_count(d_size, d_block) : 0;      // 0: block != 12 (no group index)
+        // 0: block != 12, or values of more than 32 bits (64-bit containers run on the generic kernels, which have no decode
+        // index): such files carry frame_sizes only
+        const std::size_t groups = frame_index && d_prolix_bits <= 32 ? trpx_group_count(d_size, d_block) : 0;
         if (groups && d_group_states.size() != groups * sizes.size() && !sizes.empty()) {
             std::vector<std::uint64_t> offs(sizes.size() + 1, 0);
             for (std::size_t f = 0; f < sizes.size(); ++f) offs[f + 1] = offs[f] + sizes[f];
             d_group_states.assign(groups * sizes.size(), 0);
-            const unsigned max_bits = d_prolix_bits <= 8 ? 8 : d_prolix_bits <= 16 ? 16 : 32;   // (wider data: trpx_group_states_host refuses, no group index)
-            detail::check(trpx_group_states_host(d_terse_data.data(), d_terse_data.size(), offs.data(), d_size, sizes.size(), d_block,
-                                                 max_bits, d_group_states.data(), -1), "Terse::write");
+            const unsigned max_bits = d_prolix_bits <= 8 ? 8 : d_prolix_bits <= 16 ? 16 : 32;
+            if (trpx_group_states_host(d_terse_data.data(), d_terse_data.size(), offs.data(), d_size, sizes.size(), d_block,
+                                       max_bits, d_group_states.data(), -1) != TRPX_OK)
+                d_group_states.clear();                                              // no group index: the file still gets its frame sizes
         }
         const bool with_groups = groups && d_group_states.size() == groups * sizes.size();
         std::vector<char> buf(512 + (frame_index ? 21 * d_frame_sizes.size() + (with_groups ? 16 * d_group_states.size() : 0) : 0));
@@ -220,8 +243,8 @@ private:
     std::vector<std::size_t> d_dim;
     std::vector<std::uint8_t> d_terse_data;
     std::vector<std::size_t> d_frame_sizes;
-    trpx_stack* d_stack = nullptr;                     // the stack on the device, for prolix(it, frame); dropped when frames are added
-    std::vector<std::uint64_t> d_group_states;         // chain state at every 256th block of every frame (row f1), or empty
+    mutable trpx_stack* d_stack = nullptr;             // the stack on the device, for prolix(it, frame); dropped when frames are added
+    mutable std::vector<std::uint64_t> d_group_states; // chain state at every 256th block of every frame (row f1), or empty (a cache: write() const fills it)
 
     const std::uint64_t* f_states() const {
         const std::size_t groups = trpx_group_count(d_size, d_block);

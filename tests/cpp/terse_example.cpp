@@ -24,7 +24,12 @@ int main(int argc, char** argv) {
         REQUIRE(compressed.bits_per_val() == 10);
         REQUIRE(compressed.is_signed());
         std::ostringstream hdr;
-        compressed.write(hdr);
+        const jpa::Terse& as_const = compressed;               // write() is const like the reference's (Terse.hpp:454)
+        as_const.write(hdr);
+        jpa::Terse assigned;                                   // assignable and movable like the reference class
+        assigned = compressed;
+        jpa::Terse moved(std::move(assigned));
+        REQUIRE(moved.terse_size() == compressed.terse_size() && moved.bits_per_val() == 10);
         const std::string want = "<Terse prolix_bits=\"10\" signed=\"1\" block=\"12\" memory_size=\"1152\" "
                                  "number_of_values=\"1000\" number_of_frames=\"1\"/>";
         REQUIRE(hdr.str().substr(0, want.size()) == want);

@@ -128,3 +128,22 @@ def test_host_code_survives_corrupt_input_under_asan_ubsan(tmp_path):
         if os.path.exists(path):
             os.remove(path)
     assert r.returncode == 0 and "OK host_sanitize" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_integration_md_code_blocks_are_the_compiled_snippets():
+    """INTEGRATION.md sections 2 and 4 show a maintainer the calls to write; tests/cpp/integration_snippets.cpp is those
+    blocks compiled against include/trpx_hip.h (make -C tests/cpp).  Every line of every marked snippet must appear in the
+    document, in order: a signature change that is not carried into the document fails here."""
+    import re
+    cpp = open(os.path.join(ROOT, "tests", "cpp", "integration_snippets.cpp")).read()
+    doc = [ln.strip() for ln in open(os.path.join(ROOT, "INTEGRATION.md")).read().splitlines()]
+    snippets = re.findall(r"// \[snippet:(\w+)\]\n(.*?)// \[/snippet\]", cpp, flags=re.S)
+    assert {n for n, _ in snippets} == {"include", "f_compress", "prolix", "sharded"}
+    for name, body in snippets:
+        at = 0
+        for ln in (x.strip() for x in body.splitlines()):
+            if not ln:
+                continue
+            assert ln in doc[at:], (name, ln)
+            at = doc.index(ln, at) + 1
+    assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "integration_snippets")), "make -C tests/cpp did not build it"

@@ -301,6 +301,15 @@ def test_cpp_drop_in_example(gpu, tmp_path):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_integration_md_snippets_run(gpu):
+    """INTEGRATION.md section 2's patched bodies inside a stand-in for the reference class (tests/cpp/integration_snippets.cpp)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "integration_snippets")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK integration snippets" in r.stdout, r.stdout + r.stderr
+
+
 def test_decode_index_side_channel(gpu, oracle):
     """the encoder's decode index == the index the header walk builds from the stream, and
     walk-free decode with it is pixel-identical (u16 1024-block tiles, int32 512-block tiles, ragged frame end,
@@ -1129,3 +1138,33 @@ def test_host_entry_points_from_two_threads(gpu, oracle):
     for t in threads:
         t.join(timeout=300)
     assert not errors and not any(t.is_alive() for t in threads), errors
+
+
+def test_frame_index_of_stacks_with_values_wider_than_32_bits(gpu, oracle, tmp_path):
+    """write(frame_index=True) on a stack of 64-bit pixels (what src/terse.cpp:120-123 makes of float / double
+    images) -- prolix_bits > 32, generic kernels, no decode index -- must write the frame sizes alone instead of failing, and
+    the file must read back and expand; copies / pickles of a Terse object do not share its device-side stack."""
+    import copy
+    import pickle
+    from trpx_amd import Terse
+    rng = np.random.RandomState(8)
+    px = (rng.randint(0, 1 << 20, size=(3, 600)).astype(np.int64) << 22) * rng.choice([-1, 1], size=(3, 600))
+    t = Terse()
+    t.push_back_stack(px)
+    assert t.bits_per_val() > 32
+    hdr = t.header(frame_index=True)
+    assert b"frame_sizes=" in hdr and b"group_bit_offsets" not in hdr
+    path = tmp_path / "wide.trpx"
+    with open(path, "wb") as f:
+        t.write(f, frame_index=True)
+    with open(path, "rb") as f:
+        r = Terse.read(f)
+    assert r.number_of_frames() == 3 and (r.prolix_stack(np.int64) == px).all()
+    out = np.zeros(600, np.int64)
+    r.prolix(out, 1)                                                          # opens the device-side stack
+    assert (out == px[1]).all()
+    for clone in (copy.copy(r), copy.deepcopy(r), pickle.loads(pickle.dumps(r))):
+        assert clone._stack is None
+        clone.prolix(out, 2)
+        assert (out == px[2]).all()
+    del clone, r                                                              # two closes of one handle would crash here

@@ -59,7 +59,9 @@ class Encoded:
     def check(self) -> None:
         """Synchronises and raises on a device error.  A look-back timeout of the single-pass encoder (TRPX_ERR_TIMEOUT,
         see trpx_encode_checked in include/trpx_hip.h) is not an error of the data: the call is run again through the
-        two-pass pipeline (trpx_encode_checked), which writes the identical stream."""
+        two-pass pipeline (trpx_encode_checked), which writes the identical stream -- from the pixel tensor and workspace
+        the encode was given, which this object keeps alive: ``px`` must still hold the encoded frames when ``check()`` runs
+        (a caller that recycles its pixel buffer calls ``check()`` first)."""
         code = int(self.status[0].item())
         if code == _lib.ERR_TIMEOUT and self._retry is not None:
             px, ws, block = self._retry

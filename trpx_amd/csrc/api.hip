@@ -304,6 +304,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
                             bool clear_status, void* stream) {
     trpx::FrameGeom g;
     if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: the decode index needs block=12");
+    if (is64(dtype)) return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: no decode index for 64-bit containers (generic kernels)");
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || !terse_bytes)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: bad dtype/sizes");
     if (!terse || !frame_offsets || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: null pointer");
@@ -337,6 +338,7 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     trpx::FrameGeom g;
     if (!trpx_dtype_size(out_dtype)) return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: unknown dtype %d", out_dtype);
     if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: block=%u", block);
+    if (is64(out_dtype)) return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: no decode index for 64-bit containers (generic kernels)");
     if ((stream_signed != 0) != (trpx_dtype_is_signed(out_dtype) != 0))
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: only same-signedness decode (Terse.hpp:356-357)");
     if (!geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || terse_bytes == 0)
@@ -387,6 +389,7 @@ int trpx_index_from_group_states(int dtype, const uint8_t* terse, size_t terse_b
                                  uint32_t* status, void* stream) {
     trpx::FrameGeom g;
     if (block != (unsigned)trpx::kBlock) return fail(TRPX_ERR_UNSUPPORTED, "trpx_index_from_group_states: the decode index needs block=12");
+    if (is64(dtype)) return fail(TRPX_ERR_UNSUPPORTED, "trpx_index_from_group_states: no decode index for 64-bit containers (generic kernels)");
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g) || !sizes_ok(g, n_frames) || !terse_bytes)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_index_from_group_states: bad dtype/sizes");
     if (!terse || !frame_offsets || !states || !index || !status) return fail(TRPX_ERR_INVALID_ARG, "trpx_index_from_group_states: null pointer");

@@ -148,6 +148,27 @@ class Terse:
         except Exception:
             pass
 
+    # The device-side copy of the stack (a raw trpx_stack*) belongs to ONE object: copies and pickles start without it.
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_stack"], st["_stack_len"] = None, -1
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._stack, self._stack_len = None, -1
+
+    def __copy__(self):
+        t = Terse.__new__(Terse)
+        t.__setstate__(self.__getstate__())
+        return t
+
+    def __deepcopy__(self, memo):
+        import copy
+        t = Terse.__new__(Terse)
+        t.__setstate__({k: copy.deepcopy(v, memo) for k, v in self.__getstate__().items()})
+        return t
+
     def prolix_stack(self, dtype) -> np.ndarray:
         """Decode every frame in ONE GPU call; returns [n_frames, size]."""
         f = self.number_of_frames()
@@ -207,17 +228,21 @@ class Terse:
         for i, d in enumerate(self._dim[:8]):
             h.dims[i] = d
         gs = None
-        if frame_index and self._frame_sizes and lib().trpx_group_count(self._size, self._block):
+        # (values of more than 32 bits -- 64-bit containers on the generic kernels -- have no decode index: frame sizes only)
+        if frame_index and self._frame_sizes and self._prolix_bits <= 32 and lib().trpx_group_count(self._size, self._block):
             gs = self._states()
             if gs is None:                                   # compute them once: one walk of the stack on the device
                 data = np.frombuffer(self._data, np.uint8)
                 offs = np.concatenate([[0], np.cumsum(self._frame_sizes)]).astype(np.uint64)
                 gs = np.zeros(lib().trpx_group_count(self._size, self._block) * len(self._frame_sizes), np.uint64)
                 max_bits = 8 if self._prolix_bits <= 8 else 16 if self._prolix_bits <= 16 else 32
-                check(lib().trpx_group_states_host(data.ctypes.data, data.size, offs.ctypes.data, self._size, len(self._frame_sizes),
-                                                   self._block, max_bits, gs.ctypes.data, self._device))
+                rc = lib().trpx_group_states_host(data.ctypes.data, data.size, offs.ctypes.data, self._size, len(self._frame_sizes),
+                                                  self._block, max_bits, gs.ctypes.data, self._device)
                 del data
-                self._group_states = gs
+                if rc == 0:
+                    self._group_states = gs
+                else:
+                    gs = None                                # no group index: the file still gets its frame sizes
         cap = 512 + (21 * len(self._frame_sizes) + (16 * gs.size if gs is not None else 0) if frame_index else 0)
         buf = C.create_string_buffer(cap)
         if frame_index and gs is not None:
