@@ -41,7 +41,10 @@ namespace trpx {
 template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
 // workgroups per CU (LDS image + VGPR budget).  16-bit pixels at eight: 64 VGPRs with 4 spilled, 0.281 instead of 0.270 ms;
 // 8-bit pixels at eight: 0.272 instead of 0.292 ms per noisy 2000-frame stack
-template <typename T> constexpr int fused_occupancy() { return sizeof(T) == 1 ? 8 : (sizeof(T) == 2 ? 7 : 4); }   // workgroups per CU (LDS image + VGPR budget)
+#ifndef TRPX_FUSED_OCC16
+#define TRPX_FUSED_OCC16 8
+#endif
+template <typename T> constexpr int fused_occupancy() { return sizeof(T) == 1 ? 8 : (sizeof(T) == 2 ? TRPX_FUSED_OCC16 : 4); }   // workgroups per CU (LDS image + VGPR budget)
 // Every wait on another tile is bounded in WALL time: a poll loop gives up kWaitTicks of the 100 MHz realtime counter
 // after it started (0.25 s; the whole 2000-frame launch takes 0.3 ms, so this only ever triggers when tiles do not
 // make progress at all), checked every 64 polls.  The caller then sees TRPX_ERR_TIMEOUT in status[0]
@@ -304,22 +307,38 @@ __device__ __forceinline__ void pack_payload_w(uint32_t* __restrict__ stage, uin
 #pragma unroll
     for (int j = 0; j < ND; ++j) p[j] = 0;
     if constexpr (W == 0) {
-    } else if constexpr (bits == 16) {
-        // two values per dword: y = lo | hi << W in two operations (shift, v_bfi), then 2W-bit pieces
-        constexpr uint32_t kPairMask = 2 * W >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * W) & 31)) - 1u);
+    } else if constexpr (bits == 16 && W < 16) {
+        // Two values per dword.  v_dot2_u32_u16 computes lo * c.lo + hi * c.hi + acc in one instruction: with the constants
+        // {2^s, 2^(s+W)} it places BOTH values of a dword at bit s of a running piece, and chained through the accumulator it
+        // strings L dwords together for as long as the constants fit 16 bits (s + W <= 15): W = 3 -> two chains of three
+        // dwords, 6 instructions for the 12 values (shift + v_bfi + shift + or per pair before: 18).  Sums of disjoint bit
+        // fields are ORs: every value of a block of width W is < 2^W (signed pixels are truncated to W bits first,
+        // Bit_pointer.hpp:707-710).  The kernel is bound by vector instruction issue.
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        constexpr int L = (15 - W) / (2 * W) + 1;                               // dwords per chain
+        constexpr uint32_t kPairMask = MASK | (MASK << 16);
 #pragma unroll
-        for (int j = 0; j < kBlock / 2; ++j) {
-            const uint32_t x = raw[j];
-            uint32_t y = x;
-            if constexpr (W < 16) {
-                const uint32_t t = x >> (16 - W);
-                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(MASK), "v"(x), "v"(t));   // (x & MASK) | (t & ~MASK)
-                if (PixelTraits<T>::is_signed) y &= kPairMask;                        // sign bits above the fields
+        for (int c = 0; c * L < kBlock / 2; ++c) {
+            uint32_t acc = 0;
+            int n_pairs = 0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const int j = c * L + i;
+                if (j < kBlock / 2) {
+                    union { uint32_t u; us2 v; } x, k;
+                    x.u = PixelTraits<T>::is_signed ? raw[j] & kPairMask : raw[j];
+                    k.u = (1u << (2 * W * i)) | (1u << (2 * W * i + W + 16));
+                    acc = __builtin_amdgcn_udot2(x.v, k.v, acc, false);
+                    ++n_pairs;
+                }
             }
-            const int bit = 2 * W * j;
-            p[bit >> 5] |= y << (bit & 31);
-            if ((bit & 31) + 2 * W > 32) p[(bit >> 5) + 1] |= y >> (32 - (bit & 31));
+            const int bit = 2 * W * L * c, nbits = 2 * W * n_pairs;
+            p[bit >> 5] |= acc << (bit & 31);
+            if ((bit & 31) + nbits > 32) p[(bit >> 5) + 1] |= acc >> (32 - (bit & 31));
         }
+    } else if constexpr (bits == 16) {                                          // W = 16: the dwords as they are
+#pragma unroll
+        for (int j = 0; j < kBlock / 2; ++j) p[j] = raw[j];
     } else {
 #pragma unroll
         for (int k = 0; k < kBlock; ++k) {
@@ -530,7 +549,10 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     // previous piece's last width -- then the exclusive scan of the piece sizes (tile-relative bit offsets).
     const uint32_t tile_halo = s_halo;
     uint32_t rb[kSub + 1];               // tile-relative bit where round r starts; rb[kSub] = tile bits
-    uint32_t off[kSub], wp[kSub];        // tile-relative bit position of this lane's block; its w_{b-1}
+    uint32_t off[kSub];                  // tile-relative bit position of this lane's block
+    // what the packing needs of a block besides its pixels, in ONE register per round (an eighth workgroup per CU is a matter
+    // of ~10 VGPRs): width | width of the block before << 8 | header length << 16 | full block << 24 | block exists << 25
+    uint32_t meta[kSub];
     {
         uint32_t tot = 0, h0 = 0, wprev = 0;
         if (lane < kSub * 4) {
@@ -549,8 +571,9 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
             const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)excl, r * 4 + swave);
             const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)hw, r * 4 + swave);
             off[r] = pb + (lane ? (ph & 0xFFu) : 0u) + inc[r] - len[r];
-            wp[r] = lane ? up[r] : ph >> 8;
-            hlr[r] = lane ? hlr[r] : (ph & 0xFFu);                       // lane 0's header length from the fix-up
+            const uint32_t wp_r = lane ? up[r] : ph >> 8;
+            const uint32_t hl_r = lane ? hlr[r] : (ph & 0xFFu);          // lane 0's header length from the fix-up
+            meta[r] = w[r] | (wp_r << 8) | (hl_r << 16) | (nb[r] == kBlock ? 1u << 24 : 0u) | (nb[r] ? 1u << 25 : 0u);
         }
         rb[kSub] = (uint32_t)__builtin_amdgcn_readlane((int)incl, kSub * 4 - 1);
     }
@@ -587,15 +610,16 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     auto pack_round = [&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const uint32_t pos = off[r] - bias;
-        const uint32_t hl = hlr[r];                                      // (lane 0: from the piece fix-up)
-        const uint32_t wr = w[r];
-        const uint32_t hv_top = wr == wp[r] ? 0x80000000u : s_hdr[wr];   // header code, top aligned (Terse.hpp:517-535)
-        const bool full = nb[r] == kBlock;
-        if (nb[r] && !full && !(TRPX_ABLATE & 2)) {
+        const uint32_t mr = meta[r];
+        const uint32_t hl = (mr >> 16) & 0xFFu;                          // (lane 0: from the piece fix-up)
+        const uint32_t wr = mr & 0xFFu;
+        const uint32_t hv_top = wr == ((mr >> 8) & 0xFFu) ? 0x80000000u : s_hdr[wr];   // header code, top aligned (Terse.hpp:517-535)
+        const bool full = (mr >> 24) & 1u;
+        if (((mr >> 25) & 1u) && !full && !(TRPX_ABLATE & 2)) {         // the frame's partial last block
             const uint64_t hx = (uint64_t)(hv_top >> (32u - hl)) << (pos & 31u);
             atomicOr(&s_stage[pos >> 5], (uint32_t)hx);
             if ((uint32_t)(hx >> 32)) atomicOr(&s_stage[(pos >> 5) + 1], (uint32_t)(hx >> 32));
-            if (wr) pack_payload_generic<T>(s_stage, pos + hl, wr, nb[r], pv);
+            if (wr) pack_payload_generic<T>(s_stage, pos + hl, wr, (int)nb_tail, pv);
         }
         uint64_t todo = (TRPX_ABLATE & 1) ? 0ull : __ballot(full);
         while (todo) {
