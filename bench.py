@@ -33,6 +33,7 @@ FRAMES_PER_GPU = 2000
 ENC_STAGES_TWOPASS = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
 ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
 DEC_STAGES = ["walk", "unpack"]        # tiled decode (two kernels)
+PROFILE_TAG = "r03"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
 DEC_STAGES_FRAMES = ["decode_frames", "deferred_frames"]  # one workgroup per frame (walk + extraction fused) + the frames it defers
 
 
@@ -41,7 +42,7 @@ def kernel_sources_sha16() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "trpx_amd", "csrc", "*.h*"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "trpx_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "trpx_amd", "csrc", "Makefile")]:
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
@@ -314,9 +315,9 @@ def main():
         # come from the committed profiles/ files and are only quoted while those were taken at this source state
         prof = {}
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_traffic.json")))
             if prof.get("kernel_sources_sha16") != kernel_sources_sha16():
-                prof = {"stale": f"profiles/r02_traffic.json was taken at kernel sources {prof.get('kernel_sources_sha16')}"}
+                prof = {"stale": f"profiles/{PROFILE_TAG}_traffic.json was taken at kernel sources {prof.get('kernel_sources_sha16')}"}
         except (OSError, ValueError):
             pass
 
@@ -345,7 +346,7 @@ def main():
         try:
             if args.headline_only:
                 raise RuntimeError("skipped (--headline-only)")
-            n4, f4 = 4096 * 4096, 4
+            n4, f4 = 4096 * 4096, 8                          # C4 = frames 0..7 (537 MB)
             px4 = codec.synth(np.int32, 0, f4, n4, device=dev)
             e4 = codec.encode(px4, index=True)
             torch.cuda.synchronize()

@@ -34,17 +34,21 @@
 
 namespace trpx {
 
-// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels at 6 workgroups per CU (26 KB worst-case LDS image, 64 VGPRs),
-// 3 (768 blocks) for 32-bit pixels at 4 per CU (38 KB).  Measured with the final chain design, 2000 x 512^2 u16:
-// 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms; 4096^2 i32:
-// 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
+// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels, 3 (768 blocks) for 32-bit pixels.  Measured with the round-1
+// chain design, 2000 x 512^2 u16: 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms;
+// 4096^2 i32: 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
 template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
-// workgroups per CU (LDS image + VGPR budget).  16-bit pixels at eight: 64 VGPRs with 4 spilled, 0.281 instead of 0.270 ms;
-// 8-bit pixels at eight: 0.272 instead of 0.292 ms per noisy 2000-frame stack
+// Workgroups per CU (what the VGPR budget and the half-size LDS image of fused_phase_rounds() allow).  8/16-bit pixels: eight
+// (13.4 KB image; 64 VGPRs once a round's block metadata share one register: 0.268 -> 0.258 ms per 2000-frame u16 stack against
+// seven).  32-bit pixels: five (25.7 KB image, 83 VGPRs; six means 80 VGPRs with spills: eight 4096^2 frames 0.226 instead of
+// 0.205 ms, 1000 noisy 512^2 frames 0.300 instead of 0.340 ms).
 #ifndef TRPX_FUSED_OCC16
 #define TRPX_FUSED_OCC16 8
 #endif
-template <typename T> constexpr int fused_occupancy() { return sizeof(T) == 1 ? 8 : (sizeof(T) == 2 ? TRPX_FUSED_OCC16 : 4); }   // workgroups per CU (LDS image + VGPR budget)
+#ifndef TRPX_FUSED_OCC32
+#define TRPX_FUSED_OCC32 5
+#endif
+template <typename T> constexpr int fused_occupancy() { return sizeof(T) == 1 ? 8 : (sizeof(T) == 2 ? TRPX_FUSED_OCC16 : TRPX_FUSED_OCC32); }   // workgroups per CU (LDS image + VGPR budget)
 // Every wait on another tile is bounded in WALL time: a poll loop gives up kWaitTicks of the 100 MHz realtime counter
 // after it started (0.25 s; the whole 2000-frame launch takes 0.3 ms, so this only ever triggers when tiles do not
 // make progress at all), checked every 64 polls.  The caller then sees TRPX_ERR_TIMEOUT in status[0]
