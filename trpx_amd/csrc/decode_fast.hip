@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
 // k_unpack_tiles
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 6) void k_unpack_tiles(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 5) void k_unpack_tiles(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                               uint32_t tiles_per_frame,
                                                               const uint8_t* __restrict__ widths,

@@ -8,10 +8,15 @@
 namespace trpx {
 
 template <typename T> constexpr int unpack_sub_tiles() { return sizeof(T) <= 2 ? 4 : 2; }
-// Staged (LDS-transposed) stores pay for 32-bit pixels (48-byte runs per lane: the eight 4096 x 4096 int32 frames unpack in
-// 0.12 instead of 0.29 ms); for 8/16-bit pixels the direct 8..24-byte stores are as fast and the LDS row would cost a
-// workgroup per CU (measured: 2000 x 512 x 512 u16 with index 0.311 direct / 0.321 ms staged).
+// Pixels leave through a per-wavefront LDS row as whole 128-byte lines (store_group) for every pixel type: lane-owned 8..24-byte
+// runs leave each line to be merged from several store instructions in L2, and under load the lines are written back half
+// merged (decode_frame.hip).  2000 x 512 x 512 u16 with the decode index: 0.327 ms direct, 0.291 ms staged (five instead of six
+// workgroups per CU for the rows); eight 4096 x 4096 int32 frames: 0.29 -> 0.12 ms.  TRPX_UNPACK_DIRECT: A/B build.
+#ifdef TRPX_UNPACK_DIRECT
 template <typename T> constexpr bool unpack_staged() { return sizeof(T) == 4; }
+#else
+template <typename T> constexpr bool unpack_staged() { return true; }
+#endif
 template <typename T> constexpr int unpack_stage_dwords() { return unpack_staged<T>() ? 4 * kWave * kBlock * (int)sizeof(T) / 4 : 4; }
 template <typename T>
 constexpr int unpack_image_dwords() { return unpack_sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 12; }
