@@ -180,94 +180,6 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
     }
 }
 
-// A lane that gives up its IN state for another one does not have to count its whole segment again: the chain from the new
-// state (A) and the chain it walked before (B, from `b_in`, `b_cnt` blocks up to `b_out`) merge as soon as they meet at a block
-// start with equal widths -- after a few dozen blocks on header-dense streams --, and from there on they are one chain.  Both
-// are walked in lockstep (each step advances the one that lags) until they meet: OUT stays b_out, the count is corrected by the
-// blocks the two prefixes differ in.  A that reaches `end` first, or a lane without B (`has_b` false), is an ordinary count.
-// Leaves (pos, w) = OUT state and n = count, like seg_walk<false>.
-__device__ __forceinline__ void seg_walk_merge(const SegCtx& c, uint32_t* __restrict__ win, uint32_t seg0, bool part, uint32_t end,
-                                               uint32_t& pos, uint32_t& w, uint32_t& n, bool has_b, uint64_t b_in, uint64_t b_out,
-                                               uint32_t b_cnt) {
-    const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t X = (seg0 + lane) * c.L;
-    const uint32_t oct = lane & ~7u, piece = lane & 7u;
-    uint32_t pb = (uint32_t)b_in, wb = (uint32_t)(b_in >> 32), nb = 0u;
-    bool b_live = part && has_b && pb < end;
-    bool done = !part || pos >= end;
-#ifdef TRPX_SEG_STATS
-    if (b_live) atomicAdd(c.stat + 6, 1u);
-#endif
-    seg_u4 pre[8];
-    auto fetch = [&](uint32_t t, uint64_t live) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t s = oct + k;
-            if ((live >> s) & 1ull) {
-                const uint64_t d0 = ((c.fa + (uint64_t)(seg0 + s) * c.L + (uint64_t)t * kSegAdv) >> 5) & ~3ull;
-                pre[k] = seg_load16(c, d0 + 4u * piece);
-            }
-        }
-    };
-    uint64_t live = __ballot(!done);
-    if (live) fetch(0, live);
-    for (uint32_t t = 0; live; ++t) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t s = oct + k;
-            if ((live >> s) & 1ull) *reinterpret_cast<seg_u4*>(&win[s * kSegRow + 4u * piece]) = pre[k];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        fetch(t + 1, live);
-        const uint32_t w0 = X + t * kSegAdv, wend = w0 + kSegAdv;
-        // the chain to advance: B while it lags behind A (and is still apart), else A
-        bool step_b = b_live && pb < pos;
-        uint32_t cur = step_b ? pb : pos;
-        bool act = !done && cur < wend;
-        while (__ballot(act)) {
-            const uint32_t cw = step_b ? wb : w;
-            const uint32_t li = cur - w0 + c.wsh;
-            const uint32_t dw = min(li >> 5, kSegRow - 2u);
-            const uint32_t* row = win + lane * kSegRow + dw;
-            const uint32_t bits = __builtin_amdgcn_alignbit(row[1], row[0], li);
-            const bool same = (bits & 1u) != 0u;                                          // Terse.hpp:361
-            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wbb = 10u + ((bits >> 6) & 63u);
-            const uint32_t wx = w3 != 7u ? w3 : (wa != 10u ? wa : wbb);                   // Terse.hpp:362-370
-            const uint32_t hx = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
-            uint32_t wn = same ? cw : wx;
-            wn = wn > c.max_w ? 0u : wn;
-            const bool zrun = same && wn == 0u;
-            const uint32_t ones = min((uint32_t)(__ffs((int)~bits) - 1), 32u);
-            const uint32_t rep = zrun ? min(ones, end - cur) : 1u;
-            const uint32_t len = zrun ? rep : (same ? 1u : hx) + (uint32_t)kBlock * wn;
-            if (act) {
-                if (step_b) { pb += len; nb += rep; wb = wn; }
-                else { pos += len; n += rep; w = wn; }
-            }
-            if (act && b_live && pb == pos && wb == w) {                                  // met: one chain from here on
-                pos = (uint32_t)b_out; w = (uint32_t)(b_out >> 32); n = b_cnt + n - nb;
-                done = true;
-#ifdef TRPX_SEG_STATS
-                atomicAdd(c.stat + 5, 1u);
-#endif
-            }
-#ifdef TRPX_SEG_STATS
-            if (lane == 0u) atomicAdd(c.stat + 7, 1u);
-#endif
-            b_live = b_live && !done && pb < end;                                         // (B past the segment's end: A counts on alone)
-            done = done || pos >= end || pos > c.limit;
-            step_b = b_live && pb < pos;
-            cur = step_b ? pb : pos;
-            act = !done && cur < wend;
-        }
-        __builtin_amdgcn_wave_barrier();
-        live = __ballot(!done);
-        if ((uint64_t)t * kSegAdv > (uint64_t)c.limit + 2u * kSegAdv) break;
-    }
-}
-
 // First-round guess for run-dominated streams.  Inside a run of equal-width blocks the headers are single 1 bits
 // at stride s = 1 + 12 w, and a false chain almost never merges into such a run (it would have to hit a block start
 // with the right width by chance).  So every lane looks in the first window of its segment for the smallest
@@ -388,9 +300,6 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
     bool tent = false;
     uint64_t sav_in = 0ull, sav_out = 0ull, rej = ~0ull;
     uint32_t sav_cnt = 0u;
-    bool has_old = false;                                      // (old_in, old_out, old_cnt): the chain this lane counted before it changed its IN state
-    uint64_t old_in = 0ull, old_out = 0ull;
-    uint32_t old_cnt = 0u;
     for (int iter = 0;; ++iter) {
         if (__ballot(dirty)) {
             if (iter >= max_rounds) break;                     // capped: what is still dirty / open is left to the next launch or to k_seg_resolve
@@ -399,9 +308,7 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
 #endif
             uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
             bool bad = false;
-            if (__ballot(dirty && has_old)) seg_walk_merge(c, win, 64u * k, dirty, endB, pos, w, n, has_old, old_in, old_out, old_cnt);
-            else seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
-            has_old = false;
+            seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
             if (dirty) {
                 const uint64_t o = seg_pack(pos, w);
                 if (tent) {
@@ -419,13 +326,8 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
         const bool pred_ver = lane0_true && lane <= first_open;
         const bool pred_link = lane >= 2u ? ((closed >> (lane - 1u)) & 1ull) != 0ull : lane0_true;
         const bool trusted = !strong || !walks || pred_ver || pred_link;
-        const bool counted = walks && !dirty;                  // (in, out, cnt) belong together: a chain to merge into
-        if (conflict && trusted) { has_old = counted; old_in = in; old_out = out; old_cnt = cnt; in = prev; strong = false; dirty = walks; }
-        else if (conflict && prev != rej) {
-            sav_in = in; sav_out = out; sav_cnt = cnt;
-            has_old = counted; old_in = in; old_out = out; old_cnt = cnt;
-            in = prev; tent = true; dirty = true;
-        }
+        if (conflict && trusted) { in = prev; strong = false; dirty = walks; }
+        else if (conflict && prev != rej) { sav_in = in; sav_out = out; sav_cnt = cnt; in = prev; tent = true; dirty = true; }
         if (!__ballot(dirty)) break;
     }
     if (tent) { in = sav_in; out = sav_out; cnt = sav_cnt; dirty = false; }             // (capped in the middle of a try: back to the guess)
@@ -666,11 +568,7 @@ uint32_t seg_waves_per_frame(const FrameGeom& g) {
 #else
     constexpr uint64_t kSegTargetBlocks = 96;
 #endif
-#ifdef TRPX_SEG_SMALL_K
-    if (g.n_blocks <= 32768u) return g.n_blocks >= 64u * 64u * TRPX_SEG_SMALL_K ? TRPX_SEG_SMALL_K : 1;   // (experiment: several wavefronts per small frame)
-#else
     if (g.n_blocks <= 32768u) return 1;
-#endif
     const uint64_t k = ((uint64_t)g.n_blocks + 32 * kSegTargetBlocks) / (64 * kSegTargetBlocks);
     return (uint32_t)(k ? k : 1);
 }
