@@ -204,7 +204,26 @@ def main():
     # The per-frame size gather (RCCL over xGMI -> global byte offset of every frame) depends only on the encode and
     # nothing in the decode depends on it: it runs on its own stream next to the decode and is joined at the step's end.
     # (C ABI: trpx_gather_frame_offsets = pack kernel + ncclAllGather + scan kernel on the communicator below)
-    gather = sharded.RcclSizeGather(frames, dev) if use_dist else None
+    gather, gather_kind = None, None
+    if use_dist:
+        # the C-ABI gather on its own RCCL communicator; if ANY rank cannot set it up (agreed on collectively, so that no rank
+        # waits in a collective the others never enter), every rank takes the same exchange through torch.distributed instead
+        try:
+            gather, ok = sharded.RcclSizeGather(frames, dev), 1
+        except Exception as ex:
+            print(f"bench.py rank {rank}: C-ABI RCCL gather unavailable ({ex!r})", file=sys.stderr)
+            gather, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gather_kind = "trpx_gather_frame_offsets (C ABI: pack kernel + ncclAllGather + scan kernel)"
+        else:
+            if gather is not None:
+                gather.close()
+            tg = sharded.SizeGather(frames, dev)
+            gather = lambda o, st: tg(o, st[1:2])                                     # noqa: E731
+            gather.close = lambda: None
+            gather_kind = "torch.distributed all_gather_into_tensor (fallback)"
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     def step():
@@ -438,7 +457,8 @@ def main():
             "config": {"workload": f"{frames}-frame 512x512 uint16 synth-v1 stack per GPU: Terse encode "
                                    f"(configs[1]) + Prolix decode (configs[2])",
                        "frames_per_gpu": frames, "n_values": N_VALUES, "block": 12,
-                       "parallelism": f"frames sharded {world}-way, RCCL all-gather of per-frame sizes"},
+                       "parallelism": f"frames sharded {world}-way, RCCL all-gather of per-frame sizes",
+                       "size_gather": gather_kind},
             "roundtrip_GBps_pixels": world * frames * N_VALUES * 2 * 2 * args.steps / elapsed / 1e9,
             "roofline": roofline,
         }
