@@ -29,12 +29,25 @@ sets = [("synth-v1 u16", lambda: codec.synth(np.uint16, 0, 2000, n), np.uint16),
         ("flip-every-block u16", lambda: flip(1000), np.uint16),
         ("zeros u16", lambda: torch.zeros((2000, n), device=dev, dtype=torch.int16).view(torch.uint16), np.uint16),
         ("wide u16 (10..12 bit bg)", lambda: torch.randint(0, 3000, (1000, n), device=dev, generator=g, dtype=torch.int32).to(torch.int16).view(torch.uint16), np.uint16)]
+only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, make, dt in sets:
+    if only and only not in name: continue
     px = make(); f = px.shape[0]
     ws = codec.Workspace(dev)
     enc = codec.encode(px, workspace=ws); torch.cuda.synchronize(); enc.check()
-    back, st = codec.decode(enc.data, enc.frame_offsets, n, f, dt, workspace=ws); torch.cuda.synchronize()
+    big = torch.zeros(16 + 8 * f, dtype=torch.int32, device=dev)
+    back, st = codec.decode(enc.data, enc.frame_offsets, n, f, dt, workspace=ws, status=big); torch.cuda.synchronize()
     stat = st.cpu().numpy().copy()
+    if os.environ.get("SEG_PER_FRAME"):
+        per = stat[16:].reshape(f, 8).astype(np.int64) & 0xFFFFFFFF
+        if per[:, 1].any():
+            t0 = per[:, 0].min()
+            q = [0, 10, 50, 90, 99, 100]
+            print("   per frame (us): start", np.percentile((per[:, 0] - t0) / 100, q).round(1), "rounds", np.percentile(per[:, 1] / 100, q).round(1),
+                  "write", np.percentile(per[:, 2] / 100, q).round(1), "end", np.percentile((per[:, 0] - t0 + per[:, 1] + per[:, 2]) / 100, q).round(1))
+            print("   medians (us): count passes fill", np.median(per[:, 3]) / 100, "step", np.median(per[:, 4]) / 100, "guess", np.median(per[:, 5]) / 100,
+                  "| write pass fill", np.median(per[:, 6]) / 100, "step", np.median(per[:, 7]) / 100)
+    st = st[:8].clone()
     ok = torch.equal(back.view(torch.uint8), px.contiguous().view(torch.uint8))
     L.trpx_profile_enable(1)
     buf = (C.c_float * 8)(); td = []

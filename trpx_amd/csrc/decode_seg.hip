@@ -50,6 +50,11 @@ constexpr uint32_t kSegAdv = 768;                 // bits a window advances
 constexpr uint32_t kSegRow = 36;                  // LDS dwords per lane window (16-byte aligned rows)
 constexpr uint32_t kSegSpan = 864;                // window bits a first-round guess may use (boundaries move by < kSegSpan)
 constexpr uint32_t kSegLiveMargin = 400 + kSegSpan;   // > longest block (12 + 12 * 32 bits) + boundary shift: see seg_last_live()
+#ifndef TRPX_SEG_WG
+#define TRPX_SEG_WG 0
+#endif
+constexpr bool kSegUseWg = TRPX_SEG_WG != 0;
+constexpr uint32_t kSegWgMinBlocks = 4096;        // frames of at least this many blocks are walked by two wavefronts (k_seg_listed_wg)
 
 typedef uint32_t seg_u4 __attribute__((ext_vector_type(4)));
 
@@ -62,6 +67,9 @@ struct SegCtx {
     uint32_t wsh;            // fa & 127: bit offset of a window's first wanted bit inside its 16-byte aligned load
     uint32_t n_blocks, nb_last, max_w;
     uint32_t* stat;          // status block (diagnostic build: [2] rounds, [3] wave steps, [4] lane walks)
+#ifdef TRPX_SEG_STAMPS
+    mutable uint64_t clk_wait[2] = {0, 0}, clk_step[2] = {0, 0}, clk_guess = 0;   // [WRITE]: window fill / stepping (100 MHz ticks)
+#endif
 };
 
 __device__ __forceinline__ uint64_t seg_pack(uint32_t pos, uint32_t w) { return (uint64_t)pos | ((uint64_t)w << 32); }
@@ -120,6 +128,9 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
     uint64_t live = __ballot(!done);
     if (live) fetch(0, live);
     for (uint32_t t = 0; live; ++t) {
+#ifdef TRPX_SEG_STAMPS
+        const uint64_t clk0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t s = oct + k;
@@ -129,6 +140,10 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         fetch(t + 1, live);                                   // prefetch: consumed at the top of the next iteration
+#ifdef TRPX_SEG_STAMPS
+        const uint64_t clk1 = __builtin_amdgcn_s_memrealtime();
+        c.clk_wait[WRITE] += clk1 - clk0;
+#endif
         const uint32_t w0 = X + t * kSegAdv, wend = w0 + kSegAdv;
         bool act = !done && pos < wend;
         // Every lane executes every step (no exec-mask juggling, one branch per step); a lane that is not active
@@ -136,6 +151,167 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         while (__ballot(act)) {
 #ifdef TRPX_SEG_STATS
             if (lane == 0u) atomicAdd(c.stat + 3, 1u);
+#endif
+#if !defined(TRPX_SEG_STATS) && !defined(TRPX_SEG_PLAIN_STEP)
+            if (!WRITE) {
+                // Counting steps, hand-scheduled.  A walking wavefront is bound by the LATENCY of its step -- every instruction
+                // hangs on the one before it, ~8 cycles each, plus the LDS read -- so the loop is software-pipelined around the
+                // position: the lengths of both possible headers (same width: 1 + 12 w, known from the step before; explicit:
+                // straight from the field bits) are ready when the header bit arrives, and the next step's read is issued as soon
+                // as the position is known; widths, counters and the end tests follow in its shadow (tools/stepbench.hip: 143 ->
+                // 95 ns per step at two wavefronts per SIMD; hipcc's version of the loop below: ~200 ns).
+                // The position is kept as an LDS bit address (8 * row address + bit index inside the window; rows are 16-byte
+                // aligned, so its low five bits are the funnel shift).  Lanes leave (exec) at the end of their window share or
+                // segment; the loop ends with the last lane or when a lane reads 32 one bits, which may be a run of empty blocks:
+                // the general step below takes those 32 at a time.  Widths are not checked against the pixel type here (the
+                // write pass does that: a true chain never holds a wider one, a false chain may hold anything).
+                const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;                   // pos >= end or pos > limit: done
+                const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - c.wsh);   // position -> LDS bit address
+                uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w;
+                const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
+                const uint32_t c90 = 90u, c132 = 132u;
+                uint64_t t_ex;
+                uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2;
+                asm volatile(
+                    "s_mov_b64 %[ex], exec\n\t"
+                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_scc0 9f\n\t"
+                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
+                    "v_and_b32 %[a], -4, %[a]\n\t"
+                    "ds_read2_b32 v[62:63], %[a] offset1:1\n"
+                    "1:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"           // 32 stream bits from the header on
+                    "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"                    // Terse.hpp:362-370
+                    "v_bfe_u32 %[wa], %[bits], 4, 2\n\t"
+                    "v_bfe_u32 %[wb], %[bits], 6, 6\n\t"
+                    "v_and_b32 %[t], 1, %[bits]\n\t"
+                    "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"                 // block length behind a 4-bit header
+                    "v_mad_u32_u24 %[t1], %[wa], 12, %[c90]\n\t"            //                    a 6-bit header: 6 + 12 (7 + wa)
+                    "v_mad_u32_u24 %[t2], %[wb], 12, %[c132]\n\t"           //                    a 12-bit header: 12 + 12 (10 + wb)
+                    "v_cmp_eq_u32 vcc, 3, %[wa]\n\t"
+                    "v_cndmask_b32 %[t1], %[t1], %[t2], vcc\n\t"
+                    "v_add_u32 %[wa], 7, %[wa]\n\t"
+                    "v_add_u32 %[wb], 10, %[wb]\n\t"
+                    "v_cndmask_b32 %[wa], %[wa], %[wb], vcc\n\t"
+                    "v_cmp_eq_u32 vcc, 7, %[w3]\n\t"
+                    "v_cndmask_b32 %[lx], %[lx], %[t1], vcc\n\t"
+                    "v_cndmask_b32 %[w3], %[w3], %[wa], vcc\n\t"            // width of an explicit header
+                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"                         // header bit 1: same width (Terse.hpp:361)
+                    "v_cndmask_b32 %[lx], %[lx], %[ls], vcc\n\t"
+                    "v_add_u32 %[pw], %[pw], %[lx]\n\t"
+                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
+                    "v_and_b32 %[a], -4, %[a]\n\t"
+                    "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"             // the next step's bits (lanes that leave: read and dropped)
+                    "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"
+                    "v_add_u32 %[n], 1, %[n]\n\t"
+                    "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"
+                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_scc0 9f\n\t"
+                    "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"
+                    "s_cbranch_vccz 1b\n"
+                    "9:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_mov_b64 exec, %[ex]\n"
+                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [ex] "=&s"(t_ex), [a] "=&v"(t_a), [bits] "=&v"(t_bits),
+                      [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx), [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
+                    : [stop] "v"(stop), [c90] "s"(c90), [c132] "s"(c132)
+                    : "vcc", "scc", "memory", "v62", "v63");
+                if (act) {
+                    pos = pw - k0;
+                    done = pos >= endx;
+                }
+                act = !done && pos < wend;
+                if (!__ballot(act)) break;
+            }
+            if (WRITE) {
+                // The same loop for the write pass: the width of every block goes to wf[n] (zero widths too: cheaper than a lane
+                // mask), the bit position of every 256th block to tf; lanes also leave in front of the frame's last block, which
+                // may be a partial one (the general step below knows how).
+                const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;
+                const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - c.wsh);
+                uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w, wmax = 0u;
+                const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
+                const uint32_t nstop = c.n_blocks - 1u;
+                const uint32_t c90 = 90u, c132 = 132u;
+                uint64_t t_ex, t_sv;
+                uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2;
+                asm volatile(
+                    "s_mov_b64 %[ex], exec\n\t"
+                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "v_cmp_gt_u32 vcc, %[nstop], %[n]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_scc0 9f\n\t"
+                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
+                    "v_and_b32 %[a], -4, %[a]\n\t"
+                    "ds_read2_b32 v[62:63], %[a] offset1:1\n"
+                    "1:\n\t"
+                    "v_and_b32 %[t], 0xff, %[n]\n\t"                        // block n opens a 256-block group: its header position
+                    "v_cmp_eq_u32 vcc, 0, %[t]\n\t"
+                    "s_cbranch_vccz 2f\n\t"
+                    "s_and_saveexec_b64 %[sv], vcc\n\t"
+                    "v_sub_u32 v60, %[pw], %[k0]\n\t"
+                    "v_mov_b32 v61, 0\n\t"
+                    "v_lshrrev_b32 %[t], 5, %[n]\n\t"
+                    "v_and_b32 %[t], -8, %[t]\n\t"
+                    "global_store_dwordx2 %[t], v[60:61], %[tf]\n\t"
+                    "s_mov_b64 exec, %[sv]\n"
+                    "2:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"
+                    "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"
+                    "v_bfe_u32 %[wa], %[bits], 4, 2\n\t"
+                    "v_bfe_u32 %[wb], %[bits], 6, 6\n\t"
+                    "v_and_b32 %[t], 1, %[bits]\n\t"
+                    "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"
+                    "v_mad_u32_u24 %[t1], %[wa], 12, %[c90]\n\t"
+                    "v_mad_u32_u24 %[t2], %[wb], 12, %[c132]\n\t"
+                    "v_cmp_eq_u32 vcc, 3, %[wa]\n\t"
+                    "v_cndmask_b32 %[t1], %[t1], %[t2], vcc\n\t"
+                    "v_add_u32 %[wa], 7, %[wa]\n\t"
+                    "v_add_u32 %[wb], 10, %[wb]\n\t"
+                    "v_cndmask_b32 %[wa], %[wa], %[wb], vcc\n\t"
+                    "v_cmp_eq_u32 vcc, 7, %[w3]\n\t"
+                    "v_cndmask_b32 %[lx], %[lx], %[t1], vcc\n\t"
+                    "v_cndmask_b32 %[w3], %[w3], %[wa], vcc\n\t"
+                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"
+                    "v_cndmask_b32 %[lx], %[lx], %[ls], vcc\n\t"
+                    "v_add_u32 %[pw], %[pw], %[lx]\n\t"
+                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
+                    "v_and_b32 %[a], -4, %[a]\n\t"
+                    "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"
+                    "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"
+                    "global_store_byte %[n], %[w], %[wf]\n\t"               // width[n]
+                    "v_add_u32 %[n], 1, %[n]\n\t"
+                    "v_max_u32 %[wmax], %[wmax], %[w]\n\t"
+                    "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"
+                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "v_cmp_gt_u32 vcc, %[nstop], %[n]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_scc0 9f\n\t"
+                    "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"
+                    "s_cbranch_vccz 1b\n"
+                    "9:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_mov_b64 exec, %[ex]\n"
+                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv),
+                      [a] "=&v"(t_a), [bits] "=&v"(t_bits), [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx),
+                      [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
+                    : [stop] "v"(stop), [k0] "v"(k0), [nstop] "s"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf), [tf] "s"(tf)
+                    : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
+                if (act) {
+                    pos = pw - k0;
+                    bad = bad || wmax > c.max_w;
+                    done = by_count ? n >= c.n_blocks : pos >= end;
+                    if (pos > c.limit) { bad = bad || n < c.n_blocks || !by_count; done = true; }
+                }
+                act = !done && pos < wend;
+                if (!__ballot(act)) break;
+            }
 #endif
             const uint32_t li = pos - w0 + c.wsh;                                         // bit index inside the lane's window
             const uint32_t dw = min(li >> 5, kSegRow - 2u);                               // (an inactive lane may be past its row)
@@ -146,7 +322,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             const uint32_t wx = w3 != 7u ? w3 : (wa != 10u ? wa : wb);                    // Terse.hpp:362-370
             const uint32_t hx = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
             uint32_t wn = same ? w : wx;
-            const bool wide = wn > c.max_w;
+            const bool wide = WRITE && wn > c.max_w;                                       // (counting passes take any width: see above)
             wn = wide ? 0u : wn;
             // a run of empty blocks (header bits 1, no payload: 1 bit each) is taken up to 32 blocks at a time
             const bool zrun = same && wn == 0u;
@@ -160,7 +336,9 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     bad = bad || wide;
                     if (n + rep > c.n_blocks) { bad = true; done = true; }
                     else {
+#ifndef TRPX_SEG_NO_STORE
                         if (wn) wf[n] = (uint8_t)wn;
+#endif
                         const uint32_t m = (n + (uint32_t)kTileBlocks - 1u) & ~((uint32_t)kTileBlocks - 1u);
                         if (m < n + rep) tf[m / kTileBlocks] = pos + (m - n);               // rep > 1 only for 1-bit blocks
                     }
@@ -175,6 +353,9 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             act = !done && pos < wend;
         }
         __builtin_amdgcn_wave_barrier();                      // every lane is through with this window before it is overwritten
+#ifdef TRPX_SEG_STAMPS
+        c.clk_step[WRITE] += __builtin_amdgcn_s_memrealtime() - clk1;
+#endif
         live = __ballot(!done);
         if ((uint64_t)t * kSegAdv > (uint64_t)c.limit + 2u * kSegAdv) break;   // (cannot happen: done is set past the limit)
     }
@@ -286,7 +467,13 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef TRPX_SEG_STAMPS
+        const uint64_t clkg = __builtin_amdgcn_s_memrealtime();
+#endif
         const uint64_t gs = seg_comb_guess(c, win, j * c.L);
+#ifdef TRPX_SEG_STAMPS
+        c.clk_guess += __builtin_amdgcn_s_memrealtime() - clkg;
+#endif
         if (gs != ~0ull && lane > 0u && walks) { in = gs; B = (uint32_t)gs; strong = true; }   // (lane 0: the next wave's lane 63 ends at X)
         __builtin_amdgcn_wave_barrier();
     }
@@ -413,8 +600,14 @@ __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse
     seg_zero_widths(wf, g.n_blocks, 0u, 1u);
     const SegState st = seg_state(ws, frame, 1u);
     const uint32_t jl = seg_last_live(c.limit, c.L, kWave);
+#ifdef TRPX_SEG_STAMPS
+    const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
+#endif
     seg_fixpoint(c, win, 0u, jl, true, true, 70, st);
     __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before the write pass stores widths
+#ifdef TRPX_SEG_STAMPS
+    const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint64_t in = st.in[lane];
     const uint32_t cnt = st.cnt[lane] & 0x3FFFFFFFu;
     const uint64_t next_in = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)in, 1, 64) |
@@ -422,6 +615,20 @@ __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse
     const uint32_t end = (uint32_t)__shfl_down((int)st.bnd[lane], 1, 64);
     const uint32_t base = wave_inclusive_scan(cnt) - cnt;
     seg_write(c, win, 0u, jl, in, next_in, end, base, wf, tf, c.limit / 8u, status);
+#ifdef TRPX_SEG_STAMPS
+    if (lane == 0u) {      // tools/seg_time.py passes a status block of 16 + 8 * frames words: per-frame start / rounds / write ticks (100 MHz)
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t t_c = __builtin_amdgcn_s_memrealtime();
+        status[16 + 8 * frame + 0] = (uint32_t)t_a;
+        status[16 + 8 * frame + 1] = (uint32_t)(t_b - t_a);
+        status[16 + 8 * frame + 2] = (uint32_t)(t_c - t_b);
+        status[16 + 8 * frame + 3] = (uint32_t)c.clk_wait[0];
+        status[16 + 8 * frame + 4] = (uint32_t)c.clk_step[0];
+        status[16 + 8 * frame + 5] = (uint32_t)c.clk_guess;
+        status[16 + 8 * frame + 6] = (uint32_t)c.clk_wait[1];
+        status[16 + 8 * frame + 7] = (uint32_t)c.clk_step[1];
+    }
+#endif
 }
 
 __global__ __launch_bounds__(kWave) void k_seg_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
@@ -442,6 +649,156 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
     const uint32_t i = blockIdx.x * 4u + (uint32_t)wave_id();
     if (i >= list[0]) return;
     seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, list[1 + i], win[wave_id()], status);
+}
+
+// ---- one WORKGROUP per frame (G = 64 W segments): the rounds of its W wavefronts in lockstep through LDS ------------------
+// A walking wavefront is latency bound -- a step is a chain of ~30 dependent instructions and an LDS read, ~470 cycles whatever
+// its instruction count -- and 2000 frames at one wavefront each are two wavefronts per SIMD.  Twice the segments at half the
+// length put four there and shorten every pass; the rounds need a few more iterations (a false chain more often survives a
+// shorter segment), see DESIGN.md 4.4.
+struct SegLink {                       // what the wavefronts of a frame tell each other (LDS)
+    uint64_t out_last[4];              // OUT state of each wave's lane 63
+    uint64_t closed[4];                // lanes of each wave whose link to the lane before them is closed
+    uint64_t in0[4];                   // after the rounds: IN state / boundary of each wave's lane 0, blocks counted by each wave
+    uint32_t bnd0[4], wtot[4];
+    uint32_t dirty[4];
+};
+
+// The rounds of seg_fixpoint (first launch, segment 0 true) for wave k of W; every wave of the workgroup calls it.
+__device__ __forceinline__ void seg_fixpoint_wg(const SegCtx& c, uint32_t* __restrict__ win, uint32_t k, uint32_t W, uint32_t jl,
+                                                int max_rounds, SegLink& lk, uint64_t& in_o, uint32_t& cnt_o, uint32_t& bnd_o) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t j = 64u * k + lane;
+    const bool walks = j < jl;
+    uint64_t in = seg_pack(j * c.L, 0u), out = 0ull;
+    uint32_t cnt = 0u, B = j * c.L;
+    bool strong = false, dirty = walks;
+    if (__ballot(walks)) {                                     // run-dominated streams: start inside a run (see seg_fixpoint)
+        const uint32_t oct = lane & ~7u, piece = lane & 7u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint64_t d0 = ((c.fa + (uint64_t)(64u * k + oct + q) * c.L) >> 5) & ~3ull;
+            *reinterpret_cast<seg_u4*>(&win[(oct + q) * kSegRow + 4u * piece]) = seg_load16(c, d0 + 4u * piece);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint64_t gs = seg_comb_guess(c, win, j * c.L);
+        if (gs != ~0ull && lane > 0u && walks) { in = gs; B = (uint32_t)gs; strong = true; }   // (lane 0: the wave before ends at X)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j == 0u) { in = 0ull; B = 0u; strong = false; }       // the frame starts with width 0 at bit 0 (Terse.hpp:359, :505)
+    uint32_t endB = (uint32_t)__shfl_down((int)B, 1, 64);
+    if (lane == 63u) endB = (j + 1u) * c.L;
+    bool tent = false;
+    uint64_t sav_in = 0ull, sav_out = 0ull, rej = ~0ull;
+    uint32_t sav_cnt = 0u;
+    for (int iter = 0; iter < max_rounds; ++iter) {            // (every condition that leaves the loop is workgroup-uniform)
+        if (__ballot(dirty)) {
+            uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
+            bool bad = false;
+            seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
+            if (dirty) {
+                const uint64_t o = seg_pack(pos, w);
+                if (tent) {
+                    if (o == sav_out) { out = o; cnt = n; strong = false; }          // merged: the predecessor's state is as good as mine
+                    else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; }    // back to the run guess
+                } else { out = o; cnt = n; }
+            }
+            dirty = false; tent = false;
+        }
+        if (lane == 63u) lk.out_last[k] = out;
+        __syncthreads();
+        uint64_t prev = seg_shfl_up1(out);
+        if (lane == 0u && k > 0u) prev = lk.out_last[k - 1u];
+        const bool conflict = j > 0u && j <= jl && prev != in;
+        const uint64_t closed = __ballot(!conflict);
+        if (lane == 0u) lk.closed[k] = closed;
+        __syncthreads();
+        uint32_t first_open = 64u * W;                         // the first open link of the frame: everything before it is verified
+        for (uint32_t q = W; q-- > 0u;) {
+            const uint64_t cq = lk.closed[q];
+            if (~cq) first_open = 64u * q + (uint32_t)__builtin_ctzll(~cq);
+        }
+        const bool pred_ver = j <= first_open;
+        const bool pred_link = lane >= 1u ? (j == 1u || ((closed >> (lane - 1u)) & 1ull) != 0ull)
+                                          : (k == 0u || (lk.closed[k > 0u ? k - 1u : 0u] >> 63) != 0ull);
+        const bool trusted = !strong || !walks || pred_ver || pred_link;
+        if (conflict && trusted) { in = prev; strong = false; dirty = walks; }
+        else if (conflict && prev != rej) { sav_in = in; sav_out = out; sav_cnt = cnt; in = prev; tent = true; dirty = true; }
+        const uint64_t dm = __ballot(dirty);
+        if (lane == 0u) lk.dirty[k] = dm ? 1u : 0u;
+        __syncthreads();
+        uint32_t any = 0u;
+        for (uint32_t q = 0; q < W; ++q) any |= lk.dirty[q];
+        if (!any) break;
+    }
+    if (tent) { in = sav_in; out = sav_out; cnt = sav_cnt; }   // (capped in the middle of a try: the write pass reports the open link)
+    in_o = in; cnt_o = walks ? cnt : 0u; bnd_o = B;
+}
+
+__device__ __forceinline__ void seg_frame_walk_wg(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                  const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
+                                                  uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off, uint64_t frame,
+                                                  uint32_t W, uint32_t* __restrict__ win, SegLink& lk, uint32_t* __restrict__ status) {
+    const uint32_t lane = (uint32_t)lane_id(), k = (uint32_t)wave_id();
+    SegCtx c;
+    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, W * kWave, status)) {     // (the same answer in every wave)
+        if (threadIdx.x == 0) atomicMax(&status[0], 5u);
+        return;
+    }
+    uint8_t* wf = widths + frame * g.n_blocks;
+    uint64_t* tf = tile_off + frame * g.n_tiles;
+    seg_zero_widths(wf, g.n_blocks, k, W);
+    const uint32_t jl = seg_last_live(c.limit, c.L, W * kWave);
+    uint64_t in;
+    uint32_t cnt, B;
+#ifdef TRPX_SEG_STAMPS
+    const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
+#endif
+    seg_fixpoint_wg(c, win, k, W, jl, (int)(64u * W + 6u), lk, in, cnt, B);
+#ifdef TRPX_SEG_STAMPS
+    const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t scan = wave_inclusive_scan(cnt);
+    if (lane == 63u) lk.wtot[k] = scan;
+    if (lane == 0u) { lk.in0[k] = in; lk.bnd0[k] = B; }
+    __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before any wave's write pass stores widths
+    __syncthreads();
+    uint32_t base = scan - cnt;
+    for (uint32_t q = 0; q < k; ++q) base += lk.wtot[q];
+    const bool has_next = k + 1u < W;
+    uint64_t next_in = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)in, 1, 64) |
+                       ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(in >> 32), 1, 64) << 32);
+    uint32_t end = (uint32_t)__shfl_down((int)B, 1, 64);
+    if (lane == 63u) { next_in = has_next ? lk.in0[k + 1u] : 0ull; end = has_next ? lk.bnd0[k + 1u] : 0xFFFFFFFFu; }
+    seg_write(c, win, k, jl, in, next_in, end, base, wf, tf, c.limit / 8u, status);
+#ifdef TRPX_SEG_STAMPS
+    if (threadIdx.x == 0u) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t t_c = __builtin_amdgcn_s_memrealtime();
+        status[16 + 8 * frame + 0] = (uint32_t)t_a;
+        status[16 + 8 * frame + 1] = (uint32_t)(t_b - t_a);
+        status[16 + 8 * frame + 2] = (uint32_t)(t_c - t_b);
+        status[16 + 8 * frame + 3] = (uint32_t)c.clk_wait[0];
+        status[16 + 8 * frame + 4] = (uint32_t)c.clk_step[0];
+        status[16 + 8 * frame + 5] = (uint32_t)c.clk_guess;
+        status[16 + 8 * frame + 6] = (uint32_t)c.clk_wait[1];
+        status[16 + 8 * frame + 7] = (uint32_t)c.clk_step[1];
+    }
+#endif
+}
+
+// The listed frames, one workgroup of W wavefronts each.
+template <int W>
+__global__ __launch_bounds__(W * kWave, 4) void k_seg_listed_wg(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                                 const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                                 uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                                 const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    __shared__ uint32_t win[W][kWave * kSegRow];
+    __shared__ SegLink lk;
+    if (blockIdx.x >= list[0]) return;
+    seg_frame_walk_wg(terse, terse_bytes, frame_offsets, g, max_w, widths, tile_off, list[1 + blockIdx.x], (uint32_t)W, win[wave_id()], lk, status);
 }
 
 // Tiles of the listed frames (the frames k_decode_frames gave up on -- its serial walker met an explicit header every
@@ -604,8 +961,14 @@ hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) 
 template <typename T>
 static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
-    hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
-                       a.geom, (uint32_t)PixelTraits<T>::bits, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
+    // frames of a few thousand blocks and more: two wavefronts each (k_seg_listed_wg); small ones: one, four frames to a workgroup
+    if (kSegUseWg && a.geom.n_blocks >= kSegWgMinBlocks)
+        hipLaunchKernelGGL((k_seg_listed_wg<2>), dim3((uint32_t)a.n_frames), dim3(2 * kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, (uint32_t)PixelTraits<T>::bits, a.widths, a.tile_off,
+                           static_cast<const uint32_t*>(a.defer), a.status);
+    else
+        hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
+                           a.geom, (uint32_t)PixelTraits<T>::bits, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
     const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);
     hipLaunchKernelGGL((k_unpack_listed<T>), dim3((uint32_t)(tiles < 1024 ? tiles : 1024)), dim3(kThreads), 0, st, a.terse,
