@@ -50,11 +50,6 @@ constexpr uint32_t kSegAdv = 768;                 // bits a window advances
 constexpr uint32_t kSegRow = 36;                  // LDS dwords per lane window (16-byte aligned rows)
 constexpr uint32_t kSegSpan = 864;                // window bits a first-round guess may use (boundaries move by < kSegSpan)
 constexpr uint32_t kSegLiveMargin = 400 + kSegSpan;   // > longest block (12 + 12 * 32 bits) + boundary shift: see seg_last_live()
-#ifndef TRPX_SEG_WG
-#define TRPX_SEG_WG 0
-#endif
-constexpr bool kSegUseWg = TRPX_SEG_WG != 0;
-constexpr uint32_t kSegWgMinBlocks = 4096;        // frames of at least this many blocks are walked by two wavefronts (k_seg_listed_wg)
 
 typedef uint32_t seg_u4 __attribute__((ext_vector_type(4)));
 
@@ -113,6 +108,12 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
     const uint32_t X = (seg0 + lane) * c.L;
     const uint32_t oct = lane & ~7u, piece = lane & 7u;
     bool done = !part || (WRITE && by_count ? n >= c.n_blocks : pos >= end);
+    // Counting passes do not check widths against the pixel type (the write pass does; a true chain never holds a wider one).
+    // A false chain may hold anything, and one that jumps 12 x 73 bits at a time meets the true chain late: the 6-bit field is
+    // cut to the bits a valid width needs, which bounds a false chain's blocks like the true one's (4096^2 int32 frames: 0.83 ms
+    // for the walk against 1.68 with the whole field).
+    const uint32_t wb_bits = c.max_w > 10u ? 32u - (uint32_t)__builtin_clz(c.max_w - 10u) : 0u;
+    const uint32_t wb_mask = (1u << wb_bits) - 1u;
     seg_u4 pre[8];
     // window t of segment s: dwords [d0, d0 + 32) with d0 = ((fa + X_s + 768 t) >> 5) & ~3
     auto fetch = [&](uint32_t t, uint64_t live) {
@@ -163,8 +164,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 // The position is kept as an LDS bit address (8 * row address + bit index inside the window; rows are 16-byte
                 // aligned, so its low five bits are the funnel shift).  Lanes leave (exec) at the end of their window share or
                 // segment; the loop ends with the last lane or when a lane reads 32 one bits, which may be a run of empty blocks:
-                // the general step below takes those 32 at a time.  Widths are not checked against the pixel type here (the
-                // write pass does that: a true chain never holds a wider one, a false chain may hold anything).
+                // the general step below takes those 32 at a time.
                 const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;                   // pos >= end or pos > limit: done
                 const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - c.wsh);   // position -> LDS bit address
                 uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w;
@@ -185,7 +185,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"           // 32 stream bits from the header on
                     "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"                    // Terse.hpp:362-370
                     "v_bfe_u32 %[wa], %[bits], 4, 2\n\t"
-                    "v_bfe_u32 %[wb], %[bits], 6, 6\n\t"
+                    "v_bfe_u32 %[wb], %[bits], 6, %[nb]\n\t"
                     "v_and_b32 %[t], 1, %[bits]\n\t"
                     "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"                 // block length behind a 4-bit header
                     "v_mad_u32_u24 %[t1], %[wa], 12, %[c90]\n\t"            //                    a 6-bit header: 6 + 12 (7 + wa)
@@ -217,7 +217,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     "s_mov_b64 exec, %[ex]\n"
                     : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [ex] "=&s"(t_ex), [a] "=&v"(t_a), [bits] "=&v"(t_bits),
                       [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx), [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
-                    : [stop] "v"(stop), [c90] "s"(c90), [c132] "s"(c132)
+                    : [stop] "v"(stop), [c90] "s"(c90), [c132] "s"(c132), [nb] "s"(wb_bits)
                     : "vcc", "scc", "memory", "v62", "v63");
                 if (act) {
                     pos = pw - k0;
@@ -229,15 +229,19 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             if (WRITE) {
                 // The same loop for the write pass: the width of every block goes to wf[n] (zero widths too: cheaper than a lane
                 // mask), the bit position of every 256th block to tf; lanes also leave in front of the frame's last block, which
-                // may be a partial one (the general step below knows how).
+                // may be a partial one (the general step below knows how).  Every lane's widths land in a different cache line,
+                // and a store instruction of 64 lines keeps the memory pipeline busy for longer than the rest of the step takes:
+                // four widths are collected in a register and stored as one (unaligned) dword every fourth step; what a lane
+                // holds when it leaves follows as bytes.
                 const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;
                 const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - c.wsh);
-                uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w, wmax = 0u;
+                uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w, wmax = 0u, acc = 0u, steps = 0u;
+                const uint32_t n0 = n;
                 const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
                 const uint32_t nstop = c.n_blocks - 1u;
                 const uint32_t c90 = 90u, c132 = 132u;
                 uint64_t t_ex, t_sv;
-                uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2;
+                uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2, t_st3;
                 asm volatile(
                     "s_mov_b64 %[ex], exec\n\t"
                     "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
@@ -284,8 +288,15 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     "v_and_b32 %[a], -4, %[a]\n\t"
                     "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"
                     "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"
-                    "global_store_byte %[n], %[w], %[wf]\n\t"               // width[n]
+                    "v_lshrrev_b32 %[acc], 8, %[acc]\n\t"
+                    "v_lshl_or_b32 %[acc], %[w], 24, %[acc]\n\t"            // the last four widths, oldest in the low byte
                     "v_add_u32 %[n], 1, %[n]\n\t"
+                    "s_add_u32 %[steps], %[steps], 1\n\t"
+                    "s_and_b32 %[st3], %[steps], 3\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "v_add_u32 %[t], -4, %[n]\n\t"
+                    "global_store_dword %[t], %[acc], %[wf]\n"               // width[n - 4 .. n - 1]
+                    "3:\n\t"
                     "v_max_u32 %[wmax], %[wmax], %[w]\n\t"
                     "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"
                     "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
@@ -298,12 +309,14 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     "9:\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[ex]\n"
-                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv),
+                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [acc] "+v"(acc), [steps] "+s"(steps), [st3] "=&s"(t_st3), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv),
                       [a] "=&v"(t_a), [bits] "=&v"(t_bits), [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx),
                       [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
                     : [stop] "v"(stop), [k0] "v"(k0), [nstop] "s"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf), [tf] "s"(tf)
                     : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
                 if (act) {
+                    const uint32_t held = (n - n0) & 3u;                                        // widths of blocks n - held .. n - 1, in acc's top bytes
+                    for (uint32_t q = 0; q < held; ++q) wf[n - held + q] = (uint8_t)(acc >> (8u * (4u - held + q)));
                     pos = pw - k0;
                     bad = bad || wmax > c.max_w;
                     done = by_count ? n >= c.n_blocks : pos >= end;
@@ -318,7 +331,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             const uint32_t* row = win + lane * kSegRow + dw;
             const uint32_t bits = __builtin_amdgcn_alignbit(row[1], row[0], li);          // 32 stream bits from pos
             const bool same = (bits & 1u) != 0u;                                          // Terse.hpp:361
-            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & 63u);
+            const uint32_t w3 = (bits >> 1) & 7u, wa = 7u + ((bits >> 4) & 3u), wb = 10u + ((bits >> 6) & (WRITE ? 63u : wb_mask));
             const uint32_t wx = w3 != 7u ? w3 : (wa != 10u ? wa : wb);                    // Terse.hpp:362-370
             const uint32_t hx = w3 != 7u ? 4u : (wa != 10u ? 6u : 12u);
             uint32_t wn = same ? w : wx;
@@ -651,156 +664,6 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
     seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, list[1 + i], win[wave_id()], status);
 }
 
-// ---- one WORKGROUP per frame (G = 64 W segments): the rounds of its W wavefronts in lockstep through LDS ------------------
-// A walking wavefront is latency bound -- a step is a chain of ~30 dependent instructions and an LDS read, ~470 cycles whatever
-// its instruction count -- and 2000 frames at one wavefront each are two wavefronts per SIMD.  Twice the segments at half the
-// length put four there and shorten every pass; the rounds need a few more iterations (a false chain more often survives a
-// shorter segment), see DESIGN.md 4.4.
-struct SegLink {                       // what the wavefronts of a frame tell each other (LDS)
-    uint64_t out_last[4];              // OUT state of each wave's lane 63
-    uint64_t closed[4];                // lanes of each wave whose link to the lane before them is closed
-    uint64_t in0[4];                   // after the rounds: IN state / boundary of each wave's lane 0, blocks counted by each wave
-    uint32_t bnd0[4], wtot[4];
-    uint32_t dirty[4];
-};
-
-// The rounds of seg_fixpoint (first launch, segment 0 true) for wave k of W; every wave of the workgroup calls it.
-__device__ __forceinline__ void seg_fixpoint_wg(const SegCtx& c, uint32_t* __restrict__ win, uint32_t k, uint32_t W, uint32_t jl,
-                                                int max_rounds, SegLink& lk, uint64_t& in_o, uint32_t& cnt_o, uint32_t& bnd_o) {
-    const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t j = 64u * k + lane;
-    const bool walks = j < jl;
-    uint64_t in = seg_pack(j * c.L, 0u), out = 0ull;
-    uint32_t cnt = 0u, B = j * c.L;
-    bool strong = false, dirty = walks;
-    if (__ballot(walks)) {                                     // run-dominated streams: start inside a run (see seg_fixpoint)
-        const uint32_t oct = lane & ~7u, piece = lane & 7u;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint64_t d0 = ((c.fa + (uint64_t)(64u * k + oct + q) * c.L) >> 5) & ~3ull;
-            *reinterpret_cast<seg_u4*>(&win[(oct + q) * kSegRow + 4u * piece]) = seg_load16(c, d0 + 4u * piece);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint64_t gs = seg_comb_guess(c, win, j * c.L);
-        if (gs != ~0ull && lane > 0u && walks) { in = gs; B = (uint32_t)gs; strong = true; }   // (lane 0: the wave before ends at X)
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (j == 0u) { in = 0ull; B = 0u; strong = false; }       // the frame starts with width 0 at bit 0 (Terse.hpp:359, :505)
-    uint32_t endB = (uint32_t)__shfl_down((int)B, 1, 64);
-    if (lane == 63u) endB = (j + 1u) * c.L;
-    bool tent = false;
-    uint64_t sav_in = 0ull, sav_out = 0ull, rej = ~0ull;
-    uint32_t sav_cnt = 0u;
-    for (int iter = 0; iter < max_rounds; ++iter) {            // (every condition that leaves the loop is workgroup-uniform)
-        if (__ballot(dirty)) {
-            uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
-            bool bad = false;
-            seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
-            if (dirty) {
-                const uint64_t o = seg_pack(pos, w);
-                if (tent) {
-                    if (o == sav_out) { out = o; cnt = n; strong = false; }          // merged: the predecessor's state is as good as mine
-                    else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; }    // back to the run guess
-                } else { out = o; cnt = n; }
-            }
-            dirty = false; tent = false;
-        }
-        if (lane == 63u) lk.out_last[k] = out;
-        __syncthreads();
-        uint64_t prev = seg_shfl_up1(out);
-        if (lane == 0u && k > 0u) prev = lk.out_last[k - 1u];
-        const bool conflict = j > 0u && j <= jl && prev != in;
-        const uint64_t closed = __ballot(!conflict);
-        if (lane == 0u) lk.closed[k] = closed;
-        __syncthreads();
-        uint32_t first_open = 64u * W;                         // the first open link of the frame: everything before it is verified
-        for (uint32_t q = W; q-- > 0u;) {
-            const uint64_t cq = lk.closed[q];
-            if (~cq) first_open = 64u * q + (uint32_t)__builtin_ctzll(~cq);
-        }
-        const bool pred_ver = j <= first_open;
-        const bool pred_link = lane >= 1u ? (j == 1u || ((closed >> (lane - 1u)) & 1ull) != 0ull)
-                                          : (k == 0u || (lk.closed[k > 0u ? k - 1u : 0u] >> 63) != 0ull);
-        const bool trusted = !strong || !walks || pred_ver || pred_link;
-        if (conflict && trusted) { in = prev; strong = false; dirty = walks; }
-        else if (conflict && prev != rej) { sav_in = in; sav_out = out; sav_cnt = cnt; in = prev; tent = true; dirty = true; }
-        const uint64_t dm = __ballot(dirty);
-        if (lane == 0u) lk.dirty[k] = dm ? 1u : 0u;
-        __syncthreads();
-        uint32_t any = 0u;
-        for (uint32_t q = 0; q < W; ++q) any |= lk.dirty[q];
-        if (!any) break;
-    }
-    if (tent) { in = sav_in; out = sav_out; cnt = sav_cnt; }   // (capped in the middle of a try: the write pass reports the open link)
-    in_o = in; cnt_o = walks ? cnt : 0u; bnd_o = B;
-}
-
-__device__ __forceinline__ void seg_frame_walk_wg(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                  const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
-                                                  uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off, uint64_t frame,
-                                                  uint32_t W, uint32_t* __restrict__ win, SegLink& lk, uint32_t* __restrict__ status) {
-    const uint32_t lane = (uint32_t)lane_id(), k = (uint32_t)wave_id();
-    SegCtx c;
-    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, W * kWave, status)) {     // (the same answer in every wave)
-        if (threadIdx.x == 0) atomicMax(&status[0], 5u);
-        return;
-    }
-    uint8_t* wf = widths + frame * g.n_blocks;
-    uint64_t* tf = tile_off + frame * g.n_tiles;
-    seg_zero_widths(wf, g.n_blocks, k, W);
-    const uint32_t jl = seg_last_live(c.limit, c.L, W * kWave);
-    uint64_t in;
-    uint32_t cnt, B;
-#ifdef TRPX_SEG_STAMPS
-    const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
-#endif
-    seg_fixpoint_wg(c, win, k, W, jl, (int)(64u * W + 6u), lk, in, cnt, B);
-#ifdef TRPX_SEG_STAMPS
-    const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
-#endif
-    const uint32_t scan = wave_inclusive_scan(cnt);
-    if (lane == 63u) lk.wtot[k] = scan;
-    if (lane == 0u) { lk.in0[k] = in; lk.bnd0[k] = B; }
-    __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before any wave's write pass stores widths
-    __syncthreads();
-    uint32_t base = scan - cnt;
-    for (uint32_t q = 0; q < k; ++q) base += lk.wtot[q];
-    const bool has_next = k + 1u < W;
-    uint64_t next_in = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)in, 1, 64) |
-                       ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(in >> 32), 1, 64) << 32);
-    uint32_t end = (uint32_t)__shfl_down((int)B, 1, 64);
-    if (lane == 63u) { next_in = has_next ? lk.in0[k + 1u] : 0ull; end = has_next ? lk.bnd0[k + 1u] : 0xFFFFFFFFu; }
-    seg_write(c, win, k, jl, in, next_in, end, base, wf, tf, c.limit / 8u, status);
-#ifdef TRPX_SEG_STAMPS
-    if (threadIdx.x == 0u) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const uint64_t t_c = __builtin_amdgcn_s_memrealtime();
-        status[16 + 8 * frame + 0] = (uint32_t)t_a;
-        status[16 + 8 * frame + 1] = (uint32_t)(t_b - t_a);
-        status[16 + 8 * frame + 2] = (uint32_t)(t_c - t_b);
-        status[16 + 8 * frame + 3] = (uint32_t)c.clk_wait[0];
-        status[16 + 8 * frame + 4] = (uint32_t)c.clk_step[0];
-        status[16 + 8 * frame + 5] = (uint32_t)c.clk_guess;
-        status[16 + 8 * frame + 6] = (uint32_t)c.clk_wait[1];
-        status[16 + 8 * frame + 7] = (uint32_t)c.clk_step[1];
-    }
-#endif
-}
-
-// The listed frames, one workgroup of W wavefronts each.
-template <int W>
-__global__ __launch_bounds__(W * kWave, 4) void k_seg_listed_wg(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                                 const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                                 uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
-                                                                 const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
-    __shared__ uint32_t win[W][kWave * kSegRow];
-    __shared__ SegLink lk;
-    if (blockIdx.x >= list[0]) return;
-    seg_frame_walk_wg(terse, terse_bytes, frame_offsets, g, max_w, widths, tile_off, list[1 + blockIdx.x], (uint32_t)W, win[wave_id()], lk, status);
-}
-
 // Tiles of the listed frames (the frames k_decode_frames gave up on -- its serial walker met an explicit header every
 // few blocks -- after k_seg_frames has walked them): a fixed grid strides over (listed frame, tile) pairs.
 template <typename T>
@@ -961,13 +824,7 @@ hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) 
 template <typename T>
 static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
-    // frames of a few thousand blocks and more: two wavefronts each (k_seg_listed_wg); small ones: one, four frames to a workgroup
-    if (kSegUseWg && a.geom.n_blocks >= kSegWgMinBlocks)
-        hipLaunchKernelGGL((k_seg_listed_wg<2>), dim3((uint32_t)a.n_frames), dim3(2 * kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                           a.frame_offsets, a.geom, (uint32_t)PixelTraits<T>::bits, a.widths, a.tile_off,
-                           static_cast<const uint32_t*>(a.defer), a.status);
-    else
-        hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
+    hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
                            a.geom, (uint32_t)PixelTraits<T>::bits, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
     const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);
