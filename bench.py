@@ -289,6 +289,7 @@ def main():
 
         def timed(fn, n=reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()                                              # (a kernel's first launch in a process loads its code)
             torch.cuda.synchronize()
             e0.record()
             for _ in range(n):

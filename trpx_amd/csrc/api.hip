@@ -359,7 +359,10 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     a.status = status;
     a.tile_off = reinterpret_cast<uint64_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.group_off);
     a.widths = reinterpret_cast<uint8_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.widths);
-    HIP_TRY(trpx::launch_decode_fast(out_dtype, a, true, static_cast<hipStream_t>(stream)));
+    // many small frames: one workgroup per frame (the conditions of trpx_decode's per-frame route), else the tiled kernel
+    const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
+    const bool per_frame = frame26 && g_decode_path != 2 && (g_decode_path == 3 || n_frames >= 128);
+    HIP_TRY(trpx::launch_decode_fast(out_dtype, a, true, static_cast<hipStream_t>(stream), per_frame));
     return TRPX_OK;
 }
 

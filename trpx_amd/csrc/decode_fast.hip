@@ -291,7 +291,7 @@ hipError_t launch_walk_groups(const DecodeArgs& a, uint32_t max_w, const uint64_
 }
 
 template <typename T>
-static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hipStream_t st) {
+static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, bool per_frame, hipStream_t st) {
     const FrameGeom g = a.geom;
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
     const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
@@ -305,6 +305,13 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, hip
         if (e != hipSuccess) return e;
     }
     prof.mark(st);
+    if (have_index && per_frame) {                              // many small frames: the per-frame decoder with the widths given
+        constexpr int dtype = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
+                              : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2) : (PixelTraits<T>::is_signed ? 5 : 4);
+        const hipError_t e = launch_decode_frames_indexed(dtype, a, nullptr, st);
+        prof.mark(st);
+        return e;
+    }
     hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
                        (uint64_t)a.terse_bytes, a.frame_offsets, g, tpf, a.widths, a.tile_off,
                        static_cast<T*>(a.pixels_out), a.status);
@@ -335,14 +342,14 @@ hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint3
     return hipGetLastError();
 }
 
-hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st) {
+hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st, bool per_frame) {
     switch (dtype) {
-    case 0: return launch_decode_fast_t<uint8_t>(a, have_index, st);
-    case 1: return launch_decode_fast_t<int8_t>(a, have_index, st);
-    case 2: return launch_decode_fast_t<uint16_t>(a, have_index, st);
-    case 3: return launch_decode_fast_t<int16_t>(a, have_index, st);
-    case 4: return launch_decode_fast_t<uint32_t>(a, have_index, st);
-    case 5: return launch_decode_fast_t<int32_t>(a, have_index, st);
+    case 0: return launch_decode_fast_t<uint8_t>(a, have_index, per_frame, st);
+    case 1: return launch_decode_fast_t<int8_t>(a, have_index, per_frame, st);
+    case 2: return launch_decode_fast_t<uint16_t>(a, have_index, per_frame, st);
+    case 3: return launch_decode_fast_t<int16_t>(a, have_index, per_frame, st);
+    case 4: return launch_decode_fast_t<uint32_t>(a, have_index, per_frame, st);
+    case 5: return launch_decode_fast_t<int32_t>(a, have_index, per_frame, st);
     }
     return hipErrorInvalidValue;
 }

@@ -71,11 +71,16 @@ __device__ __forceinline__ void lds_dma16(const uint32_t* src_uniform, uint32_t 
                  : "=&s"(keep) : "v"(lane_byte_offset), "s"(src_uniform), "s"(lds_base) : "memory");
 }
 
-template <typename T>
-__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
-                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
-                                                               uint32_t* __restrict__ status) {
+// IDX: the block widths are known (a decode index: widths[] and the bit offset of every 256th block, encode_kernels.hpp) and
+// wave 0 turns them into the position entries with a prefix sum instead of walking the header chain -- everything else is the
+// same kernel.  Used for trpx_decode_indexed on stacks of small frames and for the frames k_decode_frames hands to the
+// position-parallel walk, once that has written their index.
+template <typename T, bool IDX>
+__device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                  const uint64_t* __restrict__ frame_offsets, const FrameGeom& g,
+                                                  T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
+                                                  uint32_t* __restrict__ status, const uint64_t frame,
+                                                  const uint8_t* __restrict__ idx_widths, const uint64_t* __restrict__ idx_group_off) {
     using Cfg = FrameCfg<T>;
     constexpr int kStepBlocks = Cfg::kStepBlocks, kChunkDw = Cfg::kChunkDw;
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
@@ -99,7 +104,6 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
 
     const uint32_t lane = (uint32_t)lane_id();
     const int hw_wave = wave_id();
-    const uint64_t frame = blockIdx.x;
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     if (threadIdx.x == 0) s_err = (fe > fo && fe <= terse_bytes) ? 0u : 1u;
     // Which wave walks.  A workgroup's four waves land on the CU's four SIMDs, the first one on a SIMD that rotates from
@@ -160,7 +164,47 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
 #endif
     for (uint32_t s = 0; s <= n_steps; ++s) {
         if (wave == 0) {
-            if (s < n_steps) {
+            if (IDX && s < n_steps) {
+                // ---- positions from the index: H(b) for the super-step's blocks by a prefix sum over header + payload lengths ----
+                const uint32_t beg_b = step_begin(s);
+                const uint32_t end_nom = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
+                uint32_t* const ent = s_posx + (s & 1u) * kPosEntries;
+                const uint8_t* __restrict__ wf = idx_widths + frame * n_blocks;
+                constexpr int kChunks = kStepBlocks / kWave;
+                uint32_t wq[kChunks];
+#pragma unroll
+                for (int i = 0; i < kChunks; ++i) {                                    // (all loads in flight before the first is used)
+                    const uint32_t bi = beg_b + (uint32_t)i * kWave + lane;
+                    wq[i] = bi < end_nom ? (uint32_t)wf[bi] : 0u;
+                }
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < kChunks; ++i) {
+                    const uint32_t b0 = beg_b + (uint32_t)i * kWave;
+                    if (b0 >= end_nom) break;                                         // (wave-uniform)
+                    const uint32_t bi = b0 + lane, wi = wq[i];
+                    uint32_t wp = (uint32_t)__shfl_up((int)wi, 1, 64);
+                    if (lane == 0) wp = w_prev;
+                    const uint32_t hl = wi == wp ? 1u : (wi < 7u ? 4u : (wi < 10u ? 6u : 12u));   // Terse.hpp:517-535
+                    const uint32_t nv = bi + 1u == n_blocks ? nb_last : (uint32_t)kBlock;
+                    const uint32_t len = bi < end_nom ? hl + nv * wi : 0u;
+                    const uint32_t incl = wave_inclusive_scan(len);
+                    const uint32_t p = pos + incl - len;
+                    bad = bad || wi > kMaxW;
+                    if (bi < end_nom) {
+                        ent[bi - beg_b] = (frame_sh + p) | (wp << kPosBits);
+                        if ((bi & (uint32_t)(kTileBlocks - 1)) == 0u && idx_group_off[frame * g.n_tiles + bi / (uint32_t)kTileBlocks] != (uint64_t)p) bad = true;
+                    }
+                    pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    const uint32_t lastl = end_nom - b0 < (uint32_t)kWave ? end_nom - b0 - 1u : (uint32_t)kWave - 1u;
+                    w_prev = (uint32_t)__builtin_amdgcn_readlane((int)wi, (int)lastl);
+                    if (pos > limit) bad = true;                                      // (positions stay below 2^26: the index is not trusted)
+                }
+                b = end_nom;
+                if (!__ballot(bad) && b == n_blocks) bad = !(pos <= limit && 1 + (uint64_t)pos / 8 == fe - fo);   // S_f = 1 + bits/8 (Terse.hpp:547)
+                if (__ballot(bad) && lane == 0) s_err = 1u;
+                if (lane == 0) ent[b - beg_b] = (frame_sh + (pos <= limit ? pos : limit)) | (w_prev << kPosBits);
+            } else if (s < n_steps) {
                 const uint32_t buf = s & 1u;
                 const uint32_t beg_b = step_begin(s);
                 const uint32_t end_nom = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
@@ -531,7 +575,51 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
 #endif
     const bool deferred = s_err == 2u;
     if (s_err == 1u && threadIdx.x == 0) atomicMax(&status[0], 5u);        // TRPX_ERR_CORRUPT
-    if (deferred && threadIdx.x == 0) defer[1u + atomicAdd(&defer[0], 1u)] = (uint32_t)frame;   // listed: k_seg_frames + k_unpack_listed do it
+    if (deferred && threadIdx.x == 0) defer[1u + atomicAdd(&defer[0], 1u)] = (uint32_t)frame;   // listed: k_seg_listed + k_decode_frames_indexed do it
+}
+
+template <typename T>
+__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
+                                                               uint32_t* __restrict__ status) {
+    decode_frame_body<T, false>(terse, terse_bytes, frame_offsets, g, pixels_out, defer, status, blockIdx.x, nullptr, nullptr);
+}
+
+// The same with the widths given (IDX above): every frame of the stack (list == nullptr) or the frames list[1 .. list[0]].
+template <typename T>
+__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_frames_indexed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               const uint8_t* __restrict__ widths, const uint64_t* __restrict__ group_off,
+                                                               const uint32_t* __restrict__ list, T* __restrict__ pixels_out,
+                                                               uint32_t* __restrict__ status) {
+    uint64_t frame = blockIdx.x;
+    if (list) {
+        if (blockIdx.x >= list[0] || status[0] != 0u) return;
+        frame = list[1u + blockIdx.x];
+    }
+    decode_frame_body<T, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
+}
+
+template <typename T>
+static hipError_t launch_decode_frames_indexed_t(const DecodeArgs& a, const uint32_t* list, hipStream_t st) {
+    hipLaunchKernelGGL((k_decode_frames_indexed<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), list,
+                       static_cast<T*>(a.pixels_out), a.status);
+    return hipGetLastError();
+}
+
+// Per-frame decode of frames whose index (a.widths, a.tile_off) is known; same preconditions as launch_decode_frames.
+hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const uint32_t* list, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_decode_frames_indexed_t<uint8_t>(a, list, st);
+    case 1: return launch_decode_frames_indexed_t<int8_t>(a, list, st);
+    case 2: return launch_decode_frames_indexed_t<uint16_t>(a, list, st);
+    case 3: return launch_decode_frames_indexed_t<int16_t>(a, list, st);
+    case 4: return launch_decode_frames_indexed_t<uint32_t>(a, list, st);
+    case 5: return launch_decode_frames_indexed_t<int32_t>(a, list, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <typename T>

@@ -664,32 +664,6 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
     seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, list[1 + i], win[wave_id()], status);
 }
 
-// Tiles of the listed frames (the frames k_decode_frames gave up on -- its serial walker met an explicit header every
-// few blocks -- after k_seg_frames has walked them): a fixed grid strides over (listed frame, tile) pairs.
-template <typename T>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 5) void k_unpack_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
-                                                               const uint8_t* __restrict__ widths,
-                                                               const uint64_t* __restrict__ tile_off,
-                                                               const uint32_t* __restrict__ list, T* __restrict__ pixels_out,
-                                                               uint32_t* __restrict__ status) {
-    __shared__ uint32_t s_image[unpack_image_dwords<T>()];
-    __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[unpack_stage_dwords<T>()];
-    const uint32_t count = list[0];
-    if (count == 0u || status[0] != 0u) return;
-    constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
-    const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
-    const uint64_t total = (uint64_t)count * tpf;
-    for (uint64_t i = blockIdx.x; i < total; i += gridDim.x) {
-        const uint32_t frame = list[1 + (uint32_t)(i / tpf)];
-        if (!unpack_tile<T>(terse, terse_bytes, frame_offsets, g, frame, (uint32_t)(i % tpf), widths, tile_off, pixels_out, status,
-                            s_image, s_wtot, s_stage))
-            return;
-        __syncthreads();
-    }
-}
-
 // ---- several wavefronts per frame (large frames): rounds / resolve / write are separate launches -------------------------
 __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
@@ -826,11 +800,11 @@ static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) 
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
     hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
                            a.geom, (uint32_t)PixelTraits<T>::bits, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
-    constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
-    const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);
-    hipLaunchKernelGGL((k_unpack_listed<T>), dim3((uint32_t)(tiles < 1024 ? tiles : 1024)), dim3(kThreads), 0, st, a.terse,
-                       (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer),
-                       static_cast<T*>(a.pixels_out), a.status);
+    // the listed frames' pixels: the per-frame decoder again, with the widths just written in place of its walker
+    constexpr int dtype = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
+                          : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2) : (PixelTraits<T>::is_signed ? 5 : 4);
+    const hipError_t e = launch_decode_frames_indexed(dtype, a, static_cast<const uint32_t*>(a.defer), st);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -50,9 +50,10 @@ hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipS
 // converting decode (decode.hip): any integral output type with clamping, float, double; stream signedness given
 hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st);
 // tuned decode (decode_fast.hip): needs frame offsets, n_values % 4 == 0 and 16-byte aligned pixels_out
-hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st);
+hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st, bool per_frame = false);   // per_frame (with an index): k_decode_frames_indexed
 // one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
+hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const uint32_t* list, hipStream_t st);   // widths / group offsets given
 // header walk only (fills a.widths / a.tile_off from the stream): builds the decode index of an existing stack
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
