@@ -339,14 +339,25 @@ def test_decode_index_side_channel(gpu, oracle):
             assert int(st[0].item()) == 0
             assert torch.equal(back.view(torch.int32 if dt == np.int32 else torch.int16),
                                px.view(torch.int32 if dt == np.int32 else torch.int16))
-    # a wrong index is rejected, not decoded into garbage silently
+    # a wrong index is rejected, not decoded into garbage silently: by the tiled kernel (route 2) and by the per-frame
+    # decoder with the widths given (route 3; a wrong group offset, a width that is not the stream's, a width wider than the type)
     px = codec.synth(np.uint16, 0, 2, 512 * 512, device=gpu)
     enc = codec.encode(px, index=True)
-    bad = enc.index.clone()
-    bad[0:8] = 255                                         # first group offset far beyond the frame
-    back, st = codec.decode(enc.stack(), enc.frame_offsets, 512 * 512, 2, np.uint16, index=bad)
-    torch.cuda.synchronize()
-    assert int(st[0].item()) == _lib.ERR_CORRUPT
+    nb, ng = (512 * 512 + 11) // 12, ((512 * 512 + 11) // 12 + 255) // 256
+    w_off = (8 * 2 * ng + 15) // 16 * 16
+    try:
+        for route in (2, 3):
+            assert _lib.lib().trpx_set_decode_path(route) == 0
+            spoils = [("offset", slice(0, 8), 255)] if route == 2 else \
+                     [("offset", slice(8, 9), 1), ("width", slice(w_off + 5000, w_off + 5001), 1), ("wide", slice(w_off + nb + 77, w_off + nb + 78), 17)]
+            for what, where, val in spoils:
+                bad = enc.index.clone()
+                bad[where] = (bad[where] + val) if what != "wide" else val
+                back, st = codec.decode(enc.stack(), enc.frame_offsets, 512 * 512, 2, np.uint16, index=bad)
+                torch.cuda.synchronize()
+                assert int(st[0].item()) == _lib.ERR_CORRUPT, (route, what)
+    finally:
+        _lib.lib().trpx_set_decode_path(0)
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
@@ -1068,7 +1079,7 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
             px = _fuzz_stack(rng, dt, kind, n, frames)
             want, sizes, pb = oracle.encode_stack(px)
             dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
-            enc = codec.encode(dpx)
+            enc = codec.encode(dpx, index=n % 4 == 0)
             torch.cuda.synchronize()
             enc.check()
             assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb, ("encode", route, dtype, kind, n, frames)
@@ -1076,6 +1087,11 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
             torch.cuda.synchronize()
             assert int(st[0]) == 0, (route, dtype, kind, n, frames, int(st[0]))
             assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (route, dtype, kind, n, frames)
+            if enc.index is not None and route != "basic":       # walk-free: tiled kernel / per-frame decoder with the widths given
+                back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt, index=enc.index)
+                torch.cuda.synchronize()
+                assert int(st[0]) == 0, ("index", route, dtype, kind, n, frames, int(st[0]))
+                assert (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), ("index", route, dtype, kind, n, frames)
     finally:
         L.trpx_set_decode_path(0)
 
