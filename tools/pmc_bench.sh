@@ -16,7 +16,7 @@ for i in (1,2,3):
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         k=r["Kernel_Name"].split("(")[0]
-        if "k_decode_frames" in k or "k_encode_fused" in k:
+        if "k_decode_frames<" in k or "k_encode_fused" in k:
             acc[(k[:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k,c),v in sorted(acc.items()): print(f"${tag} {k:40s} {c:14s} n={len(v):3d} mean={sum(v)/len(v):14.1f} min={min(v):14.1f} max={max(v):14.1f}")
 PY

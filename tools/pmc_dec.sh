@@ -19,7 +19,7 @@ for i in (1,2,3,4):
     f=fs[0]
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_decode_frames" in r["Kernel_Name"]:
+        if "k_decode_frames<" in r["Kernel_Name"]:     # (not k_decode_frames_indexed: the empty deferral launch)
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in sorted(acc.items()): print(f"{k:36s} n={len(v):3d} mean={sum(v)/len(v):16.1f}")
 PY

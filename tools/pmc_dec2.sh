@@ -16,7 +16,7 @@ for i in (1,2,3,4):
     if not fs: print("pass", i, "failed"); continue
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "k_decode_frames" in r["Kernel_Name"]:
+        if "k_decode_frames<" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in sorted(acc.items()): print(f"${tag} {k:28s} n={len(v):3d} mean={sum(v)/len(v):16.1f}")
 PY
