@@ -34,19 +34,27 @@
 
 namespace trpx {
 
-// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels, 3 (768 blocks) for 32-bit pixels.  Measured with the round-1
-// chain design, 2000 x 512^2 u16: 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms;
-// 4096^2 i32: 2 @ 6 / 3 @ 4 -> 0.29 / 0.225 ms.
-template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? 4 : 3; }
+// sub-tiles per tile: 4 (1024 blocks) for 8/16-bit pixels, 5 (1280 blocks, 60 KB of pixels) for 32-bit pixels.  Measured with the
+// round-1 chain design, 2000 x 512^2 u16: 3 @ 8 / 4 @ 6 / 5 @ 4 / 6 @ 4 sub-tiles @ workgroups per CU -> 0.40 / 0.325 / 0.38 / 0.354 ms;
+// round 3, u16: 4 @ 8 / 5 @ 6 / 6 @ 5 / 5 @ 7 (6 VGPRs spilled) / 6 @ 6 (17 spilled) -> 0.258 / 0.253 / 0.256 / 0.270 / 0.277 ms (kept: 4 @ 8);
+// round 3, eight 4096^2 int32 frames: 2 @ 6..8 / 3 @ 5 / 4 @ 4 / 5 @ 4 / 6 @ 3 -> 0.29 / 0.208 / 0.173 / 0.164 / 0.166 ms, 1000 noisy
+// 512^2 int32 frames 0.39-0.44 / 0.333 / 0.272 / 0.249 / 0.260 ms: a 32-bit tile's fixed costs (look-back, flush, two barriers) weigh
+// more than the workgroups its registers cost.
+#ifndef TRPX_FUSED_SUB32
+#define TRPX_FUSED_SUB32 5
+#endif
+#ifndef TRPX_FUSED_SUB16
+#define TRPX_FUSED_SUB16 4
+#endif
+template <typename T> constexpr int sub_tiles() { return sizeof(T) <= 2 ? TRPX_FUSED_SUB16 : TRPX_FUSED_SUB32; }
 // Workgroups per CU (what the VGPR budget and the half-size LDS image of fused_phase_rounds() allow).  8/16-bit pixels: eight
 // (13.4 KB image; 64 VGPRs once a round's block metadata share one register: 0.268 -> 0.258 ms per 2000-frame u16 stack against
-// seven).  32-bit pixels: five (25.7 KB image, 83 VGPRs; six means 80 VGPRs with spills: eight 4096^2 frames 0.226 instead of
-// 0.205 ms, 1000 noisy 512^2 frames 0.300 instead of 0.340 ms).
+// seven).  32-bit pixels: four (five sub-tiles: 38.4 KB image, 117 VGPRs; with three sub-tiles: five workgroups, 83 VGPRs).
 #ifndef TRPX_FUSED_OCC16
 #define TRPX_FUSED_OCC16 8
 #endif
 #ifndef TRPX_FUSED_OCC32
-#define TRPX_FUSED_OCC32 5
+#define TRPX_FUSED_OCC32 4
 #endif
 template <typename T> constexpr int fused_occupancy() { return sizeof(T) == 1 ? 8 : (sizeof(T) == 2 ? TRPX_FUSED_OCC16 : TRPX_FUSED_OCC32); }   // workgroups per CU (LDS image + VGPR budget)
 // Every wait on another tile is bounded in WALL time: a poll loop gives up kWaitTicks of the 100 MHz realtime counter
