@@ -1048,6 +1048,14 @@ def _fuzz_stack(rng, dt, kind, n, frames):
         hi = np.where(rng.rand(frames, nblk) < 0.02, rng.randint(0, top + 1, size=(frames, nblk)), 3 if top >= 3 else 1)   # runs + outliers
     elif kind == 3:
         hi = np.where(rng.rand(frames, nblk) < 0.5, 2, 3 if top >= 3 else 1)                          # flips every other block
+    elif kind == 5:                                                                                    # payloads of one bits: a header position
+        hi = np.repeat(rng.randint(0, min(top, 12) + 1, size=(frames, (nblk + 39) // 40)), 40, axis=1)[:, :nblk]   # may read 0xFFFFFFFF
+        sat = np.repeat(hi, 12, axis=1)[:, :n]
+        mag = np.where(rng.rand(frames, n) < 0.97, (1 << sat) - 1, 0).astype(np.int64)
+        mag[:, n // 2: n // 2 + n // 5] = 0                                                             # and a run of empty blocks
+        if dt.kind == "i":
+            return np.where(mag > 0, -1, 0).astype(dt) * (rng.rand(frames, n) < 0.9) + (rng.randint(-40, 40, size=(frames, n)) * (rng.rand(frames, n) < 0.01)).astype(dt)
+        return mag.astype(dt)
     else:
         hi = np.repeat(rng.randint(0, top + 1, size=(frames, (nblk + 299) // 300)), 300, axis=1)[:, :nblk]   # long runs of changing widths
     mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
@@ -1071,7 +1079,8 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
     tdt = {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
            4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
     rng = np.random.RandomState(1000 * _ROUTES[route] + ALL_DTYPES.index(dtype))
-    cases = [(0, 4096, 3), (1, 12 * 768 + 4, 17), (2, 40000, 130), (3, 3000, 140), (4, 131072, 3), (2, 388, 129), (1, 52, 2)]
+    cases = [(0, 4096, 3), (1, 12 * 768 + 4, 17), (2, 40000, 130), (3, 3000, 140), (4, 131072, 3), (2, 388, 129), (1, 52, 2),
+             (5, 50000, 131), (5, 262144, 4)]
     assert L.trpx_set_decode_path(9) != 0                                    # out of range: refused
     try:
         assert L.trpx_set_decode_path(_ROUTES[route]) == 0
