@@ -11,6 +11,16 @@ enc = codec.encode(px, workspace=ws); torch.cuda.synchronize(); enc.check()
 total = enc.total_bytes()
 back, st = codec.decode(enc.data, enc.frame_offsets, n, frames, np.int32, workspace=ws); torch.cuda.synchronize()
 assert int(st[0].item()) == 0 and torch.equal(back, px)
+if os.environ.get("SEG_PER_WAVE"):      # a -DTRPX_SEG_STAMPS build: per wavefront of the first k_seg_round launch
+    big = torch.zeros(16 + 8 * 4096, dtype=torch.int32, device="cuda")
+    codec.decode(enc.data, enc.frame_offsets, n, frames, np.int32, out=back, workspace=ws, status=big); torch.cuda.synchronize()
+    per = big.cpu().numpy()[16:].reshape(-1, 8).astype(np.int64) & 0xFFFFFFFF
+    per = per[per[:, 1] > 0]
+    q = [0, 10, 50, 90, 100]
+    t0 = per[:, 0].min()
+    print("waves", len(per), "start us", np.percentile((per[:, 0] - t0) / 100, q).round(1), "total us", np.percentile(per[:, 1] / 100, q).round(1),
+          "fill", np.percentile(per[:, 3] / 100, q).round(1), "step", np.percentile(per[:, 4] / 100, q).round(1),
+          "guess", np.percentile(per[:, 5] / 100, q).round(1), "rounds", np.percentile(per[:, 6], q))
 L.trpx_profile_enable(1)
 buf = (C.c_float * 8)(); e, d = [], []
 for _ in range(5):

@@ -64,6 +64,7 @@ struct SegCtx {
     uint32_t* stat;          // status block (diagnostic build: [2] rounds, [3] wave steps, [4] lane walks)
 #ifdef TRPX_SEG_STAMPS
     mutable uint64_t clk_wait[2] = {0, 0}, clk_step[2] = {0, 0}, clk_guess = 0;   // [WRITE]: window fill / stepping (100 MHz ticks)
+    mutable uint32_t clk_rounds = 0;
 #endif
 };
 
@@ -508,6 +509,9 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
 #endif
             uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
             bool bad = false;
+#ifdef TRPX_SEG_STAMPS
+            ++c.clk_rounds;
+#endif
             seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
             if (dirty) {
                 const uint64_t o = seg_pack(pos, w);
@@ -680,7 +684,17 @@ __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__
     if (first) seg_zero_widths(widths + frame * g.n_blocks, g.n_blocks, k, K);
     const uint32_t jl = seg_last_live(c.limit, c.L, K * kWave);
     // (rounds per launch: 3 / 5 / 8 / 12 / 24 -> 37 (frames left to the serial walk) / 1.09 / 0.81 / 0.73 / 0.80 ms for eight 4096^2 frames)
+#ifdef TRPX_SEG_STAMPS
+    const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
+#endif
     seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, 12, seg_state(ws, frame, K));
+#ifdef TRPX_SEG_STAMPS
+    if (first && threadIdx.x == 0) {                            // tools/c4_time.py (SEG_PER_WAVE=1): status block of 16 + 8 * waves words
+        uint32_t* o = status + 16 + 8 * blockIdx.x;
+        o[0] = (uint32_t)t_a; o[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_a);
+        o[3] = (uint32_t)c.clk_wait[0]; o[4] = (uint32_t)c.clk_step[0]; o[5] = (uint32_t)c.clk_guess; o[6] = c.clk_rounds;
+    }
+#endif
 }
 
 // One wavefront per frame: closes the links the rounds left open -- between the frame's waves and inside them --
