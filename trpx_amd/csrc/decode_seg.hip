@@ -397,20 +397,28 @@ __device__ __forceinline__ uint64_t seg_comb_guess(const SegCtx& c, const uint32
         if (a == 0xFFFFFFFFu) best = seg_pack(X, 0u);
     }
     const uint32_t w_hi = c.max_w < 4u ? c.max_w : 4u;
-    for (uint32_t w = 1; w <= w_hi; ++w) {
-        const uint32_t s = 1u + (uint32_t)kBlock * w;
-        const uint32_t r0 = 560u / s, R = r0 < 12u ? 12u : (r0 > 32u ? 32u : r0);
-        const uint32_t fit = kSegSpan - (R - 1u) * s - 12u, range = w < 3u ? (4u * s < fit ? 4u * s : fit) : fit;
-        const uint32_t words = (range + 31u) / 32u;
-        for (uint32_t i = 0; i < words; ++i) {
-            uint32_t a = i + 1u == words && (range & 31u) ? (1u << (range & 31u)) - 1u : 0xFFFFFFFFu;
-            for (uint32_t k = 0; k < R; ++k) {
-                const uint32_t q = c.wsh + 32u * i + k * s;                                   // (wave-uniform)
-                a &= __builtin_amdgcn_alignbit(row[(q >> 5) + 1u], row[q >> 5], q);
+    // Second pass, for the lanes the first left without a guess in a stream that is run-dominated (others did find one): half
+    // the evidence.  A peak inside the 560 bits -- two explicit headers -- leaves a lane on a false chain that does not merge
+    // before the next explicit header, about a segment away, and every such lane in a row costs the wavefront a round.
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+        const uint32_t evid = pass ? 250u : 560u, rmin = pass ? 8u : 12u;
+        for (uint32_t w = 1; w <= w_hi; ++w) {
+            const uint32_t s = 1u + (uint32_t)kBlock * w;
+            const uint32_t r0 = evid / s, R = r0 < rmin ? rmin : (r0 > 32u ? 32u : r0);
+            const uint32_t fit = kSegSpan - (R - 1u) * s - 12u, range = w < 3u ? (4u * s < fit ? 4u * s : fit) : fit;
+            const uint32_t words = (range + 31u) / 32u;
+            for (uint32_t i = 0; i < words; ++i) {
+                uint32_t a = i + 1u == words && (range & 31u) ? (1u << (range & 31u)) - 1u : 0xFFFFFFFFu;
+                for (uint32_t k = 0; k < R; ++k) {
+                    const uint32_t q = c.wsh + 32u * i + k * s;                               // (wave-uniform)
+                    a &= __builtin_amdgcn_alignbit(row[(q >> 5) + 1u], row[q >> 5], q);
+                }
+                if (a && best == ~0ull) best = seg_pack(X + 32u * i + (uint32_t)__builtin_ctz(a), w);
             }
-            if (a && best == ~0ull) best = seg_pack(X + 32u * i + (uint32_t)__builtin_ctz(a), w);
+            if (!__ballot(best == ~0ull)) break;
         }
-        if (!__ballot(best == ~0ull)) break;
+        const uint64_t none = __ballot(best == ~0ull);
+        if (!none || __builtin_popcountll(~none) < 8) break;                  // all served, or not a run-dominated stream
     }
     return best;
 }
