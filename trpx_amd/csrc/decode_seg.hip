@@ -695,7 +695,9 @@ __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__
 #ifdef TRPX_SEG_STAMPS
     const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
 #endif
-    seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, 12, seg_state(ws, frame, K));
+    // (the first launch, where no wavefront but the frame's first knows its lane 0 is right, stops after 4 rounds: what is open then
+    // closes faster with the links of the second launch -- 2 / 3 / 4 / 6 / 8 / 12 rounds: 0.58 / 0.59 / 0.46 / 0.50 / 0.50 / 0.54 ms)
+    seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, first ? 4 : 12, seg_state(ws, frame, K));
 #ifdef TRPX_SEG_STAMPS
     if (first && threadIdx.x == 0) {                            // tools/c4_time.py (SEG_PER_WAVE=1): status block of 16 + 8 * waves words
         uint32_t* o = status + 16 + 8 * blockIdx.x;
