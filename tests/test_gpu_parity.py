@@ -1067,6 +1067,35 @@ def _fuzz_stack(rng, dt, kind, n, frames):
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_build_index_of_many_small_frames(gpu, oracle, dtype):
+    """trpx_build_index on a stack of >= 128 small frames runs the per-frame walker with index writers in place of the extraction
+    (k_index_frames; header-dense frames go to the position-parallel walk): the index must equal the one the encoder writes as a
+    by-product, block for block and group for group, and decode the stack (Terse.hpp:360-372 has one chain per frame)."""
+    import torch
+    from trpx_amd import codec
+    dt = np.dtype(dtype)
+    tdt = {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
+           4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
+    rng = np.random.RandomState(4242 + ALL_DTYPES.index(dtype))
+    for kind, n, frames in ((2, 40000, 130), (3, 12 * 1024 + 8, 140), (1, 3000, 200), (5, 50000, 131), (0, 52, 129)):
+        px = _fuzz_stack(rng, dt, kind, n, frames)
+        dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
+        enc = codec.encode(dpx, index=True)
+        torch.cuda.synchronize()
+        enc.check()
+        walked = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, dt)
+        torch.cuda.synchronize()
+        nb = (n + 11) // 12
+        ng = (nb + 255) // 256
+        w_off = (8 * frames * ng + 15) // 16 * 16
+        assert torch.equal(enc.index[: 8 * frames * ng], walked[: 8 * frames * ng]), (dtype, kind, n, frames, "group offsets")
+        assert torch.equal(enc.index[w_off: w_off + frames * nb], walked[w_off: w_off + frames * nb]), (dtype, kind, n, frames, "widths")
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt, index=walked)
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, kind, n, frames)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 @pytest.mark.parametrize("route", sorted(_ROUTES))
 def test_decode_route_matrix(gpu, oracle, route, dtype):
     """Each decode route forced through trpx_set_decode_path (the basic kernels, the position-parallel walk + tiled

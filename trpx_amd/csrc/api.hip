@@ -86,13 +86,14 @@ int g_decode_path = [] {
     if (!e) return 0;
     return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3 : 0;
 }();
-struct IdxLayout { size_t group_off, widths, seg, total; };
+struct IdxLayout { size_t group_off, widths, seg, defer, total; };
 IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     IdxLayout l;
     l.group_off = 0;
     l.widths = trpx::align_up(8 * n_frames * (size_t)g.n_tiles, 16);
     l.seg = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);   // scratch of trpx_build_index's walk
-    l.total = l.seg + trpx::seg_workspace_bytes(g, n_frames);
+    l.defer = l.seg + trpx::seg_workspace_bytes(g, n_frames);                 // list of the frames the per-frame walker hands over
+    l.total = l.defer + trpx::align_up(4 * (n_frames + 2), 256);
     return l;
 }
 struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, total; };
@@ -323,6 +324,10 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     a.tile_off = reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off);
     a.widths = reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths);
     a.seg_ws = static_cast<char*>(index) + il.seg;
+    a.defer = reinterpret_cast<uint32_t*>(static_cast<char*>(index) + il.defer);
+    // many small frames: the per-frame decoder's walker writes the index (the conditions of trpx_decode's per-frame route)
+    a.index_per_frame = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) + (1u << 17) < (1ull << 26) && g_decode_path != 2 &&
+                        (g_decode_path == 3 || n_frames >= 128);
     HIP_TRY(trpx::launch_walk_only(a, (uint32_t)(8 * trpx_dtype_size(dtype)), clear_status, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }

@@ -332,6 +332,8 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
 #else
     constexpr bool lds_walk = false;
 #endif
+    if (!lds_walk && a.seg_ws && a.index_per_frame && a.defer && seg_single_wave(a.geom))
+        return launch_index_frames(max_w, a, false, st);        // (status cleared above if asked)
     if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, st);
     return launch_walk_lds_only(a, max_w, nullptr, st);
 }

@@ -71,17 +71,20 @@ __device__ __forceinline__ void lds_dma16(const uint32_t* src_uniform, uint32_t 
                  : "=&s"(keep) : "v"(lane_byte_offset), "s"(src_uniform), "s"(lds_base) : "memory");
 }
 
-// IDX: the block widths are known (a decode index: widths[] and the bit offset of every 256th block, encode_kernels.hpp) and
-// wave 0 turns them into the position entries with a prefix sum instead of walking the header chain -- everything else is the
-// same kernel.  Used for trpx_decode_indexed on stacks of small frames and for the frames k_decode_frames hands to the
-// position-parallel walk, once that has written their index.
-template <typename T, bool IDX>
+// MODE 0: decode.  MODE 1: the block widths are known (a decode index: widths[] and the bit offset of every 256th block,
+// encode_kernels.hpp) and wave 0 turns them into the position entries with a prefix sum instead of walking the header chain --
+// everything else is the same kernel; used for trpx_decode_indexed on stacks of small frames and for the frames k_decode_frames
+// hands to the position-parallel walk, once that has written their index.  MODE 2: the walker walks, and the other waves write
+// the index (widths, group offsets) instead of pixels: trpx_build_index on stacks of small frames (header-dense frames are
+// handed to the position-parallel walk like in MODE 0).
+template <typename T, int MODE>
 __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                   const uint64_t* __restrict__ frame_offsets, const FrameGeom& g,
                                                   T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
                                                   uint32_t* __restrict__ status, const uint64_t frame,
                                                   const uint8_t* __restrict__ idx_widths, const uint64_t* __restrict__ idx_group_off) {
     using Cfg = FrameCfg<T>;
+    constexpr bool IDX = MODE == 1;
     constexpr int kStepBlocks = Cfg::kStepBlocks, kChunkDw = Cfg::kChunkDw;
     constexpr uint32_t kMaxW = PixelTraits<T>::bits;
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kChunkDw + 4];  // walker's window of the stream
@@ -445,6 +448,15 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     w = pw >> kPosBits;
                     q = (pw & kPosMask) - (blk + 1u == n_blocks ? nb_last : (uint32_t)kBlock) * w;   // first payload bit, relative to dword frame_dw
                 }
+                if constexpr (MODE == 2) {                                            // the index instead of the pixels
+                    if (blk < step1) {
+                        const_cast<uint8_t*>(idx_widths)[frame * n_blocks + blk] = (uint8_t)w;
+                        if ((blk & (uint32_t)(kTileBlocks - 1)) == 0u)
+                            const_cast<uint64_t*>(idx_group_off)[frame * g.n_tiles + blk / (uint32_t)kTileBlocks] =
+                                (uint64_t)((ent[blk - step0] & kPosMask) - frame_sh);
+                    }
+                    continue;
+                }
                 const uint32_t dq = q >> 5, sq = q & 31u;
                 const uint32_t last_dw = (uint32_t)__builtin_amdgcn_readlane((int)dq, 63) + (uint32_t)kRawDw;   // lanes ascend in position
                 uint32_t raw[kRawDw];
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
                                                                uint32_t* __restrict__ status) {
-    decode_frame_body<T, false>(terse, terse_bytes, frame_offsets, g, pixels_out, defer, status, blockIdx.x, nullptr, nullptr);
+    decode_frame_body<T, 0>(terse, terse_bytes, frame_offsets, g, pixels_out, defer, status, blockIdx.x, nullptr, nullptr);
 }
 
 // The same with the widths given (IDX above): every frame of the stack (list == nullptr) or the frames list[1 .. list[0]].
@@ -598,7 +610,32 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
         if (blockIdx.x >= list[0] || status[0] != 0u) return;
         frame = list[1u + blockIdx.x];
     }
-    decode_frame_body<T, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
+    decode_frame_body<T, 1>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
+}
+
+// The index of every frame of a stack of small frames (MODE 2 above); T stands for the width limit only.
+template <typename T>
+__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_index_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               uint8_t* __restrict__ widths, uint64_t* __restrict__ group_off,
+                                                               uint32_t* __restrict__ defer, uint32_t* __restrict__ status) {
+    decode_frame_body<T, 2>(terse, terse_bytes, frame_offsets, g, static_cast<T*>(nullptr), defer, status, blockIdx.x, widths, group_off);
+}
+
+// Writes a.widths / a.tile_off with the per-frame walker; the frames it lists in a.defer are left to launch_seg_listed.
+hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_status, hipStream_t st) {
+    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(a.defer), (uint64_t)1,
+                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0));
+    if (max_w <= 8u)
+        hipLaunchKernelGGL((k_index_frames<uint8_t>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, a.widths, a.tile_off, a.defer, a.status);
+    else if (max_w <= 16u)
+        hipLaunchKernelGGL((k_index_frames<uint16_t>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, a.widths, a.tile_off, a.defer, a.status);
+    else
+        hipLaunchKernelGGL((k_index_frames<uint32_t>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, a.widths, a.tile_off, a.defer, a.status);
+    return launch_seg_listed(a, max_w, st);
 }
 
 template <typename T>

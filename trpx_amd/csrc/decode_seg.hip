@@ -824,11 +824,18 @@ hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) 
 }
 
 
-template <typename T>
-static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
+// The decode index of the frames listed in a.defer (one wavefront per listed frame; needs seg_single_wave(a.geom)).
+hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
     hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
-                           a.geom, (uint32_t)PixelTraits<T>::bits, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
+                       a.geom, max_w, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
+    const hipError_t e0 = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
+    if (e0 != hipSuccess) return e0;
     // the listed frames' pixels: the per-frame decoder again, with the widths just written in place of its walker
     constexpr int dtype = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
                           : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2) : (PixelTraits<T>::is_signed ? 5 : 4);

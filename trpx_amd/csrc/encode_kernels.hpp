@@ -38,6 +38,7 @@ struct DecodeArgs {
     uint64_t*       walk_offsets;  // n_frames + 1 : frame offsets produced by the serial walk
     uint32_t*       defer;         // 2 + n_frames words, 8-byte aligned (may be null): [0] = count, [1 + i] = frames the per-frame decoder hands to the position-parallel path
     void*           seg_ws;        // seg_workspace_bytes(): segment states of the position-parallel walk (decode_seg.hip)
+    bool            index_per_frame = false;   // launch_walk_only: many small frames, use the per-frame walker (launch_index_frames)
 };
 
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
@@ -54,6 +55,8 @@ hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, h
 // one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const uint32_t* list, hipStream_t st);   // widths / group offsets given
+hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_status, hipStream_t st);   // the index by the per-frame walker (needs a.defer, a.seg_ws)
+hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st);                       // decode_seg.hip: index of the frames listed in a.defer
 // header walk only (fills a.widths / a.tile_off from the stream): builds the decode index of an existing stack
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
