@@ -322,6 +322,7 @@ def main():
                 for i, name in enumerate(dec_names[:k]):
                     acc.setdefault(name, []).append(buf[i])
             L.trpx_profile_enable(0)
+            stages.samples = acc                               # (roof() reports the spread of the launches next to their mean)
             return {k: float(np.mean(v)) for k, v in acc.items()}
 
         stage_ms = stages(lambda: codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e),
@@ -341,10 +342,16 @@ def main():
         except (OSError, ValueError):
             pass
 
-        def roof(kernel, ms):
+        head_samples = dict(stages.samples)
+
+        def roof(kernel, ms, stage=None):
             r = {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": alg_bytes / ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                  "avg_launch_ms": ms}
+            v = head_samples.get(stage)
+            if v:                                              # the launches of the timed round trips: how far they spread
+                r.update({"launches": len(v), "launch_ms_std": float(np.std(v)), "launch_ms_min": float(np.min(v)),
+                          "launch_ms_max": float(np.max(v))})
             k = prof.get(kernel)
             if k and frames == FRAMES_PER_GPU:
                 r["traffic"] = k.get("traffic_bytes")
@@ -355,11 +362,11 @@ def main():
             return r
 
         ekey = "encode_fused" if "encode_fused" in stage_ms else "pack"
-        roofs = {"encode": roof({"encode_fused": "k_encode_fused<uint16_t>", "pack": "k_pack<uint16_t>"}[ekey], stage_ms[ekey])}
+        roofs = {"encode": roof({"encode_fused": "k_encode_fused<uint16_t>", "pack": "k_pack<uint16_t>"}[ekey], stage_ms[ekey], ekey)}
         if "decode_frames" in stage_ms:
-            roofs["decode"] = roof("k_decode_frames<uint16_t>", stage_ms["decode_frames"])
+            roofs["decode"] = roof("k_decode_frames<uint16_t>", stage_ms["decode_frames"], "decode_frames")
         elif "unpack" in stage_ms:
-            roofs["decode"] = roof("k_unpack_tiles<uint16_t>", stage_ms["unpack"])
+            roofs["decode"] = roof("k_unpack_tiles<uint16_t>", stage_ms["unpack"], "unpack")
 
         # configs[3] (informative, not part of `value`): 4096x4096 int32 frames with sparse peaks, 1 GPU
         c4 = {}

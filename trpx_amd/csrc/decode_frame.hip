@@ -104,11 +104,17 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     if (terse_bytes == 1) s_pad[threadIdx.x] = 0;
 #endif
     __shared__ uint32_t s_role[kFrameWaves];
+    // What only the epilogue needs (status / list pointers, the frame number) waits in LDS: as live scalar registers across the
+    // super-step loop they were spilled to a VGPR's lanes (the kernel sits at the 80-SGPR limit of eight workgroups per CU).
+    __shared__ uint64_t s_keep[3];
 
     const uint32_t lane = (uint32_t)lane_id();
     const int hw_wave = wave_id();
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
-    if (threadIdx.x == 0) s_err = (fe > fo && fe <= terse_bytes) ? 0u : 1u;
+    if (threadIdx.x == 0) {
+        s_err = (fe > fo && fe <= terse_bytes) ? 0u : 1u;
+        s_keep[0] = (uint64_t)(uintptr_t)status; s_keep[1] = (uint64_t)(uintptr_t)defer; s_keep[2] = frame;
+    }
     // Which wave walks.  A workgroup's four waves land on the CU's four SIMDs, the first one on a SIMD that rotates from
     // workgroup to workgroup, and the k-th workgroup to arrive on a CU gets wave slot k on every SIMD (measured,
     // tools/hwid.hip).  "The wave whose SIMD number equals its slot number mod 4 walks" puts exactly two of a CU's eight
@@ -585,9 +591,13 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #ifdef TRPX_DEC_NO_STORE
     if (diag_acc == 0x12345678u) fout[threadIdx.x] = (T)diag_acc;
 #endif
-    const bool deferred = s_err == 2u;
-    if (s_err == 1u && threadIdx.x == 0) atomicMax(&status[0], 5u);        // TRPX_ERR_CORRUPT
-    if (deferred && threadIdx.x == 0) defer[1u + atomicAdd(&defer[0], 1u)] = (uint32_t)frame;   // listed: k_seg_listed + k_decode_frames_indexed do it
+    if (threadIdx.x == 0 && s_err != 0u) {
+        asm volatile("" ::: "memory");                                     // (the LDS copies, not the registers they came from)
+        uint32_t* const status_l = reinterpret_cast<uint32_t*>((uintptr_t)s_keep[0]);
+        uint32_t* const defer_l = reinterpret_cast<uint32_t*>((uintptr_t)s_keep[1]);
+        if (s_err == 1u) atomicMax(&status_l[0], 5u);                      // TRPX_ERR_CORRUPT
+        if (s_err == 2u) defer_l[1u + atomicAdd(&defer_l[0], 1u)] = (uint32_t)s_keep[2];   // listed: k_seg_listed + k_decode_frames_indexed do it
+    }
 }
 
 template <typename T>
