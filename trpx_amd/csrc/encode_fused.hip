@@ -219,13 +219,32 @@ template <> struct QuadVec<int32_t>  { typedef uint32_t type __attribute__((ext_
 // tile 768..6144 positions further on, issued after barrier #1 -- was measured: 0.32-0.39 ms instead of 0.31.)
 template <typename T>
 __device__ __forceinline__ void load_raw_nt(const T* __restrict__ p, uint32_t (&raw)[Raw<T>::dw]) {
+    // 16-bit pixels: 24 bytes as 16 + 8, 8-bit pixels: 12 bytes in one load (dword alignment is all a global load needs; three
+    // 8-byte / 4-byte loads: 0.268 instead of 0.266 ms per 2000-frame stack).  Plain loads: non-temporal ones cost this kernel 12 %
+    // (0.30 ms) -- they do leave the freshly written stream in the caches for a decode that follows (0.23-0.24 instead of 0.25-0.27
+    // ms), which does not pay the difference back.
+    if constexpr (sizeof(T) == 2) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        u4 lo; u2 hi;
+        __builtin_memcpy(&lo, p, 16);
+        __builtin_memcpy(&hi, reinterpret_cast<const char*>(p) + 16, 8);
+        raw[0] = lo.x; raw[1] = lo.y; raw[2] = lo.z; raw[3] = lo.w; raw[4] = hi.x; raw[5] = hi.y;
+        return;
+    } else if constexpr (sizeof(T) == 1) {
+        typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+        u3 x;
+        __builtin_memcpy(&x, p, 12);
+        raw[0] = x.x; raw[1] = x.y; raw[2] = x.z;
+        return;
+    }
     using V = typename QuadVec<T>::type;
     constexpr int q = Raw<T>::dw / 3;
     const V* src = reinterpret_cast<const V*>(p);
     union U { V vec; uint32_t x[q]; };
     U a, b, c;
-    a.vec = src[0];                                       // plain loads: measured 5 % faster than non-temporal ones here
-    b.vec = src[1];                                       // (0.311 vs 0.328 ms per 2000-frame stack)
+    a.vec = src[0];
+    b.vec = src[1];
     c.vec = src[2];
 #pragma unroll
     for (int i = 0; i < q; ++i) { raw[i] = a.x[i]; raw[q + i] = b.x[i]; raw[2 * q + i] = c.x[i]; }
