@@ -409,7 +409,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                         if ((uint32_t)i < per) changes += (ent[at] >> kPosBits) != (ent[at + 1] >> kPosBits) ? 1u : 0u;
                     }
                     const uint32_t inc = wave_inclusive_scan(changes);
-                    if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) * 6u > per * kWave && lane == 0) s_err = 2u;
+                    const uint32_t chg = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    if (chg * 6u > per * kWave && lane == 0) s_err = chg * 3u > per * kWave ? 3u : 2u;   // (3: a change every third block and more)
                 }
             }
         } else if (s >= 1) {
@@ -596,7 +597,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
         uint32_t* const status_l = reinterpret_cast<uint32_t*>((uintptr_t)s_keep[0]);
         uint32_t* const defer_l = reinterpret_cast<uint32_t*>((uintptr_t)s_keep[1]);
         if (s_err == 1u) atomicMax(&status_l[0], 5u);                      // TRPX_ERR_CORRUPT
-        if (s_err == 2u) defer_l[1u + atomicAdd(&defer_l[0], 1u)] = (uint32_t)s_keep[2];   // listed: k_seg_listed + k_decode_frames_indexed do it
+        // listed: k_seg_listed + k_decode_frames_indexed do it (bit 31: so dense that a search for runs is a waste of time)
+        if (s_err >= 2u) defer_l[1u + atomicAdd(&defer_l[0], 1u)] = (uint32_t)s_keep[2] | (s_err == 3u ? 0x80000000u : 0u);
     }
 }
 
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
     uint64_t frame = blockIdx.x;
     if (list) {
         if (blockIdx.x >= list[0] || status[0] != 0u) return;
-        frame = list[1u + blockIdx.x];
+        frame = list[1u + blockIdx.x] & 0x7FFFFFFFu;
     }
     decode_frame_body<T, 1>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
 }

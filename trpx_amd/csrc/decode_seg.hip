@@ -468,7 +468,7 @@ struct SegState {
 // ends where its own did (merged: nothing downstream changes), else it returns to its guess and waits.
 // The first open link of a wave with a true lane 0 is always taken, so the loop ends with all links closed there.
 __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restrict__ win, uint32_t k, uint32_t jl, bool first,
-                                             bool lane0_true, int max_rounds, const SegState& st) {
+                                             bool lane0_true, int max_rounds, const SegState& st, bool run_guess = true) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t j = 64u * k + lane;
     const bool walks = j < jl;                                 // lane jl and the lanes behind it own no counted blocks
@@ -479,7 +479,7 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
         in = st.in[j]; out = st.out[j]; B = st.bnd[j];
         const uint32_t cs = st.cnt[j];
         cnt = cs & 0x3FFFFFFFu; strong = (cs >> 31) != 0u; dirty = ((cs >> 30) & 1u) != 0u && walks;   // (left dirty by a capped launch)
-    } else if (__ballot(walks)) {                              // run-dominated streams: start inside a run
+    } else if (run_guess && __ballot(walks)) {                 // run-dominated streams: start inside a run
         const uint32_t oct = lane & ~7u, piece = lane & 7u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -613,7 +613,8 @@ __device__ __forceinline__ SegState seg_state(const SegWs& w, uint64_t frame, ui
 __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
                                                const SegWs& ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
-                                               uint64_t frame, uint32_t* __restrict__ win, uint32_t* __restrict__ status) {
+                                               uint64_t frame, uint32_t* __restrict__ win, uint32_t* __restrict__ status,
+                                               bool run_guess = true) {
     const uint32_t lane = (uint32_t)lane_id();
     SegCtx c;
     if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, kWave, status)) {
@@ -628,7 +629,7 @@ __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse
 #ifdef TRPX_SEG_STAMPS
     const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
 #endif
-    seg_fixpoint(c, win, 0u, jl, true, true, 70, st);
+    seg_fixpoint(c, win, 0u, jl, true, true, 70, st, run_guess);
     __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before the write pass stores widths
 #ifdef TRPX_SEG_STAMPS
     const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
@@ -673,7 +674,9 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
     __shared__ uint32_t win[4][kWave * kSegRow];
     const uint32_t i = blockIdx.x * 4u + (uint32_t)wave_id();
     if (i >= list[0]) return;
-    seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, list[1 + i], win[wave_id()], status);
+    const uint32_t entry = list[1 + i];                        // bit 31: a width change every third block and more -- no run to look for
+    seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, entry & 0x7FFFFFFFu, win[wave_id()], status,
+                   (entry >> 31) == 0u);
 }
 
 // ---- several wavefronts per frame (large frames): rounds / resolve / write are separate launches -------------------------
