@@ -285,6 +285,9 @@ hipError_t launch_index_group_states(const DecodeArgs& a, uint64_t* states, hipS
 hipError_t launch_walk_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, bool clear_status, hipStream_t st) {
     if (clear_status) zero_status(a.status, st);
     const uint64_t n = (uint64_t)a.n_frames * a.geom.n_tiles;
+    // frames of less than 2^32 bits: the write pass of the position-parallel walk, one lane per group (k_seg_groups)
+    const uint64_t worst_bits = (uint64_t)a.geom.n_blocks * (12u + (uint64_t)kBlock * max_w) + 8u;
+    if (worst_bits < 0xF0000000ull) return launch_seg_groups(a, max_w, states, st);
     hipLaunchKernelGGL(k_walk_groups, dim3((uint32_t)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, a.terse,
                        (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w, states, n, a.widths, a.tile_off, a.status);
     return hipGetLastError();

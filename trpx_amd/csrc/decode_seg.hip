@@ -101,14 +101,26 @@ __device__ __forceinline__ seg_u4 seg_load16(const SegCtx& c, uint64_t d) {
 //   WRITE == false: count the block starts in [pos, end); leaves (pos, w) = OUT state, n = count.
 //   WRITE == true : n is the global block index; stores widths / group offsets; a lane with by_count set stops
 //                   at n == n_blocks (the frame's last blocks) instead of at `end`.
+//   org (optional): where the lane's windows start and where a by_count lane stops, if not at the segment boundary (seg0 + lane) L
+//                   and at n_blocks -- the walk of 256-block groups from their recorded start states (k_seg_groups).
+struct SegOrigin {
+    uint32_t X;          // bit position (inside the frame) of the lane's window 0
+    uint32_t n_end;      // a by_count lane stops at n == n_end
+};
+
 template <bool WRITE>
 __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__ win, uint32_t seg0, bool part, uint32_t end,
                                          bool by_count, uint32_t& pos, uint32_t& w, uint32_t& n,
-                                         uint8_t* __restrict__ wf, uint64_t* __restrict__ tf, bool& bad) {
+                                         uint8_t* __restrict__ wf, uint64_t* __restrict__ tf, bool& bad, const SegOrigin* org = nullptr) {
     const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t X = (seg0 + lane) * c.L;
+    const uint32_t X = org ? org->X : (seg0 + lane) * c.L;
+    const uint32_t wsh = org ? (uint32_t)((c.fa + X) & 127u) : c.wsh;      // bit offset of the window's first wanted bit in its 16-byte aligned load
+    const uint32_t n_end = org ? org->n_end : c.n_blocks;
     const uint32_t oct = lane & ~7u, piece = lane & 7u;
-    bool done = !part || (WRITE && by_count ? n >= c.n_blocks : pos >= end);
+    uint32_t Xo[8];                                            // window origins of the eight rows this lane helps to load
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Xo[k] = org ? (uint32_t)__shfl((int)X, (int)(oct + k), 64) : (seg0 + oct + (uint32_t)k) * c.L;
+    bool done = !part || (WRITE && by_count ? n >= n_end : pos >= end);
     // Counting passes do not check widths against the pixel type (the write pass does; a true chain never holds a wider one).
     // A false chain may hold anything, and one that jumps 12 x 73 bits at a time meets the true chain late: the 6-bit field is
     // cut to the bits a valid width needs, which bounds a false chain's blocks like the true one's (4096^2 int32 frames: 0.83 ms
@@ -122,7 +134,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         for (int k = 0; k < 8; ++k) {
             const uint32_t s = oct + k;
             if ((live >> s) & 1ull) {
-                const uint64_t d0 = ((c.fa + (uint64_t)(seg0 + s) * c.L + (uint64_t)t * kSegAdv) >> 5) & ~3ull;
+                const uint64_t d0 = ((c.fa + (uint64_t)Xo[k] + (uint64_t)t * kSegAdv) >> 5) & ~3ull;
                 pre[k] = seg_load16(c, d0 + 4u * piece);
             }
         }
@@ -167,7 +179,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 // segment; the loop ends with the last lane or when a lane reads 32 one bits, which may be a run of empty blocks:
                 // the general step below takes those 32 at a time.
                 const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;                   // pos >= end or pos > limit: done
-                const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - c.wsh);   // position -> LDS bit address
+                const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - wsh);   // position -> LDS bit address
                 uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w;
                 const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
                 const uint32_t c90 = 90u, c132 = 132u;
@@ -235,11 +247,11 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 // four widths are collected in a register and stored as one (unaligned) dword every fourth step; what a lane
                 // holds when it leaves follows as bytes.
                 const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;
-                const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - c.wsh);
+                const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - wsh);
                 uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w, wmax = 0u, acc = 0u, steps = 0u;
                 const uint32_t n0 = n;
                 const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
-                const uint32_t nstop = c.n_blocks - 1u;
+                const uint32_t nstop = n_end - 1u;                                               // (n_end >= 1)
                 const uint32_t c90 = 90u, c132 = 132u;
                 uint64_t t_ex, t_sv;
                 uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2, t_st3;
@@ -313,21 +325,21 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [acc] "+v"(acc), [steps] "+s"(steps), [st3] "=&s"(t_st3), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv),
                       [a] "=&v"(t_a), [bits] "=&v"(t_bits), [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx),
                       [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
-                    : [stop] "v"(stop), [k0] "v"(k0), [nstop] "s"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf), [tf] "s"(tf)
+                    : [stop] "v"(stop), [k0] "v"(k0), [nstop] "v"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf), [tf] "s"(tf)
                     : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
                 if (act) {
                     const uint32_t held = (n - n0) & 3u;                                        // widths of blocks n - held .. n - 1, in acc's top bytes
                     for (uint32_t q = 0; q < held; ++q) wf[n - held + q] = (uint8_t)(acc >> (8u * (4u - held + q)));
                     pos = pw - k0;
                     bad = bad || wmax > c.max_w;
-                    done = by_count ? n >= c.n_blocks : pos >= end;
-                    if (pos > c.limit) { bad = bad || n < c.n_blocks || !by_count; done = true; }
+                    done = by_count ? n >= n_end : pos >= end;
+                    if (pos > c.limit) { bad = bad || n < n_end || !by_count; done = true; }
                 }
                 act = !done && pos < wend;
                 if (!__ballot(act)) break;
             }
 #endif
-            const uint32_t li = pos - w0 + c.wsh;                                         // bit index inside the lane's window
+            const uint32_t li = pos - w0 + wsh;                                           // bit index inside the lane's window
             const uint32_t dw = min(li >> 5, kSegRow - 2u);                               // (an inactive lane may be past its row)
             const uint32_t* row = win + lane * kSegRow + dw;
             const uint32_t bits = __builtin_amdgcn_alignbit(row[1], row[0], li);          // 32 stream bits from pos
@@ -341,7 +353,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             // a run of empty blocks (header bits 1, no payload: 1 bit each) is taken up to 32 blocks at a time
             const bool zrun = same && wn == 0u;
             const uint32_t ones = min((uint32_t)(__ffs((int)~bits) - 1), 32u);
-            const uint32_t room = WRITE && by_count ? c.n_blocks - n : end - pos;
+            const uint32_t room = WRITE && by_count ? n_end - n : end - pos;
             const uint32_t rep = zrun ? min(ones, room) : 1u;
             const uint32_t nv = WRITE && n + 1u == c.n_blocks ? c.nb_last : (uint32_t)kBlock;
             const uint32_t len = zrun ? rep : (same ? 1u : hx) + nv * wn;
@@ -361,8 +373,8 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             pos = act ? pos + len : pos;
             n = act ? n + rep : n;
             w = act ? wn : w;
-            done = done || (act && (WRITE && by_count ? n >= c.n_blocks : pos >= end));
-            if (WRITE) { if (act && pos > c.limit) bad = bad || n < c.n_blocks || !by_count; }
+            done = done || (act && (WRITE && by_count ? n >= n_end : pos >= end));
+            if (WRITE) { if (act && pos > c.limit) bad = bad || n < n_end || !by_count; }
             done = done || pos > c.limit;
             act = !done && pos < wend;
         }
@@ -677,6 +689,68 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
     const uint32_t entry = list[1 + i];                        // bit 31: a width change every third block and more -- no run to look for
     seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, entry & 0x7FFFFFFFu, win[wave_id()], status,
                    (entry >> 31) == 0u);
+}
+
+// ---- the index from recorded group states (row f1 for files): the write pass alone --------------------------------------------
+// The chain state at every 256th block (trpx_index_group_states / the group_bit_offsets header attribute) makes every group a
+// segment with a verified IN state: one lane per group walks it by count with the write pass's windows and steps, 64 consecutive
+// groups of a frame to a wavefront.  Every group is checked against its successor's state, the last one against S_f = 1 + bits/8
+// (Terse.hpp:547).  (k_walk_groups, decode_fast.hip, reads its headers straight from global memory: ~0.85 us per dependent step
+// against ~0.17 here; it stays for frames of 2^32 bits and more.)
+__global__ __launch_bounds__(kThreads) void k_seg_groups(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                         const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                         uint32_t n_frames, const uint64_t* __restrict__ states,
+                                                         uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                         uint32_t* __restrict__ status) {
+    __shared__ uint32_t win[4][kWave * kSegRow];
+    constexpr uint64_t kOffMask = (1ull << 40) - 1;
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t wpf = (g.n_tiles + (uint32_t)kWave - 1u) / (uint32_t)kWave;       // wavefronts per frame
+    const uint64_t wv = (uint64_t)blockIdx.x * 4u + (uint32_t)wave_id();
+    const uint64_t frame = wv / wpf;
+    if (frame >= n_frames) return;
+    const uint32_t k = (uint32_t)(wv % wpf) * (uint32_t)kWave + lane;                // this lane's group
+    SegCtx c;
+    if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, kWave, status)) {
+        if (lane == 0) atomicMax(&status[0], 5u);
+        return;
+    }
+    uint8_t* wf = widths + frame * g.n_blocks;
+    uint64_t* tf = tile_off + frame * g.n_tiles;
+    const bool part = k < g.n_tiles;
+    const uint64_t st = part ? states[frame * g.n_tiles + k] : 0ull;
+    const uint32_t b0 = k * (uint32_t)kTileBlocks;
+    const uint32_t b1 = part ? (b0 + (uint32_t)kTileBlocks < g.n_blocks ? b0 + (uint32_t)kTileBlocks : g.n_blocks) : b0;
+    uint32_t pos = (uint32_t)(st & kOffMask), w = (uint32_t)(st >> 40), n = b0;
+    bool bad = part && ((k == 0u && st != 0ull) || (st & kOffMask) > (uint64_t)c.limit || w > max_w);   // (a frame starts at bit 0 with width 0)
+    // the general step leaves empty blocks to the zeroes: this wavefront's stretch of the width array first
+    {
+        const uint32_t z0 = (uint32_t)(wv % wpf) * (uint32_t)kWave * (uint32_t)kTileBlocks;
+        const uint32_t z1 = z0 + (uint32_t)(kWave * kTileBlocks) < g.n_blocks ? z0 + (uint32_t)(kWave * kTileBlocks) : g.n_blocks;
+        const uint64_t a0 = (uint64_t)(uintptr_t)(wf + z0);
+        const uint32_t head = (uint32_t)((16u - (a0 & 15u)) & 15u) < z1 - z0 ? (uint32_t)((16u - (a0 & 15u)) & 15u) : z1 - z0;
+        const uint32_t n16 = (z1 - z0 - head) / 16u;
+        if (lane < head) wf[z0 + lane] = 0;
+        if (z0 + head + 16u * n16 + lane < z1) wf[z0 + head + 16u * n16 + lane] = 0;                     // < 16 bytes
+        seg_u4* q = reinterpret_cast<seg_u4*>(wf + z0 + head);
+        const seg_u4 z = {0u, 0u, 0u, 0u};
+        for (uint32_t i = lane; i < n16; i += kWave) q[i] = z;
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    const SegOrigin org{pos, b1};
+    seg_walk<true>(c, win[wave_id()], 0u, part && !bad && b1 > b0, 0xFFFFFFFFu, true, pos, w, n, wf, tf, bad, &org);
+    if (part && !bad) {
+        if (b1 < g.n_blocks) bad = ((uint64_t)pos | ((uint64_t)w << 40)) != states[frame * g.n_tiles + k + 1u];   // lands in the next group's state
+        else bad = !(n == g.n_blocks && pos <= c.limit && 1u + pos / 8u == c.limit / 8u);                          // S_f
+    }
+    if (__ballot(bad) && lane == 0u) atomicMax(&status[0], 5u);                          // TRPX_ERR_CORRUPT
+}
+
+hipError_t launch_seg_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, hipStream_t st) {
+    const uint64_t waves = (uint64_t)a.n_frames * ((a.geom.n_tiles + kWave - 1) / kWave);
+    hipLaunchKernelGGL(k_seg_groups, dim3((uint32_t)((waves + 3) / 4)), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, a.geom, max_w, a.n_frames, states, a.widths, a.tile_off, a.status);
+    return hipGetLastError();
 }
 
 // ---- several wavefronts per frame (large frames): rounds / resolve / write are separate launches -------------------------

@@ -57,6 +57,7 @@ hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const uint32_t* list, hipStream_t st);   // widths / group offsets given
 hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_status, hipStream_t st);   // the index by the per-frame walker (needs a.defer, a.seg_ws)
 hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st);                       // decode_seg.hip: index of the frames listed in a.defer
+hipError_t launch_seg_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, hipStream_t st);   // decode_seg.hip: index from group states (frames < 2^32 bits)
 // header walk only (fills a.widths / a.tile_off from the stream): builds the decode index of an existing stack
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
