@@ -34,5 +34,29 @@ for c in range(cases):
     assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb, ("encode", c, dt, n, frames, kind)
     back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt); torch.cuda.synchronize()
     assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), ("decode", c, dt, n, frames, kind, int(st[0]))
+    if n % 4 == 0 and os.environ.get("TRPX_DECODE_PATH", "") != "basic":
+        # the decode index three ways: the encoder's by-product, trpx_build_index, rebuilt from the group states -- all equal, all decode
+        from trpx_amd import _lib
+        L = _lib.lib()
+        enc_i = codec.encode(dpx, index=True); torch.cuda.synchronize(); enc_i.check()
+        walked = codec.build_index(enc_i.stack(), enc_i.frame_offsets, n, frames, dt); torch.cuda.synchronize()
+        ng = (nblk + 255) // 256
+        w_off = (8 * frames * ng + 15) // 16 * 16
+        for what, other in (("build_index", walked),):
+            assert torch.equal(enc_i.index[: 8 * frames * ng], other[: 8 * frames * ng]), (what, "group offsets", c, dt, n, frames, kind)
+            assert torch.equal(enc_i.index[w_off: w_off + frames * nblk], other[w_off: w_off + frames * nblk]), (what, "widths", c, dt, n, frames, kind)
+        states = torch.zeros(frames * ng, dtype=torch.int64, device="cuda")
+        _lib.check(L.trpx_index_group_states(enc_i.index.data_ptr(), n, frames, 12, states.data_ptr(), None))
+        rebuilt = torch.zeros_like(enc_i.index)
+        st8 = torch.zeros(8, dtype=torch.int32, device="cuda")
+        stack = enc_i.stack()
+        _lib.check(L.trpx_index_from_group_states(codec.dtype_code(TDT[dt.type]), stack.data_ptr(), stack.numel(), enc_i.frame_offsets.data_ptr(),
+                                                  states.data_ptr(), n, frames, 12, rebuilt.data_ptr(), st8.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert int(st8[0]) == 0, ("group states", c, dt, n, frames, kind, int(st8[0]))
+        assert torch.equal(enc_i.index[: 8 * frames * ng], rebuilt[: 8 * frames * ng]) and \
+            torch.equal(enc_i.index[w_off: w_off + frames * nblk], rebuilt[w_off: w_off + frames * nblk]), ("group states", c, dt, n, frames, kind)
+        back, st = codec.decode(stack, enc_i.frame_offsets, n, frames, dt, index=rebuilt); torch.cuda.synchronize()
+        assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), ("indexed decode", c, dt, n, frames, kind, int(st[0]))
     if c % 20 == 0: print(f"case {c} ok ({time.time() - t0:.0f} s)", flush=True)
 print(f"OK {cases} cases, path {os.environ.get('TRPX_DECODE_PATH', 'default')}")
