@@ -1,4 +1,4 @@
-"""Decode with the decode index (k_unpack_tiles alone) and noisy-stack decode: quick timing."""
+"""Decode with the decode index (k_decode_frames_indexed for stacks of small frames, k_unpack_tiles otherwise) and noisy-stack decode: quick timing."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
