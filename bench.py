@@ -327,7 +327,7 @@ def main():
 
         stage_ms = stages(lambda: codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e),
                           lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d),
-                          DEC_STAGES_FRAMES if frames >= 128 else DEC_STAGES)
+                          DEC_STAGES_FRAMES)
         pix_bytes = frames * N_VALUES * 2
         alg_bytes = pix_bytes + total_bytes                    # B_enc = B_dec = N*sizeof(T) + S_f per frame
 

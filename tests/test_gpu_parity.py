@@ -1109,7 +1109,7 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
            4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
     rng = np.random.RandomState(1000 * _ROUTES[route] + ALL_DTYPES.index(dtype))
     cases = [(0, 4096, 3), (1, 12 * 768 + 4, 17), (2, 40000, 130), (3, 3000, 140), (4, 131072, 3), (2, 388, 129), (1, 52, 2),
-             (5, 50000, 131), (5, 262144, 4)]
+             (5, 50000, 131), (5, 262144, 4), (2, 12 * 40000 + 8, 3)]      # (the last one: > 32 K blocks, several wavefronts per frame on the tiled route)
     assert L.trpx_set_decode_path(9) != 0                                    # out of range: refused
     try:
         assert L.trpx_set_decode_path(_ROUTES[route]) == 0

@@ -282,16 +282,17 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
 #endif
     a.defer = no_defer ? nullptr : reinterpret_cast<uint32_t*>(ws + w.defer);
     const int route = g_decode_path;                                          // trpx_set_decode_path / $TRPX_DECODE_PATH
-    const bool basic = route == 1, force_tiles = route == 2, force_frames = route == 3;
+    const bool basic = route == 1, force_tiles = route == 2;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
     const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0 &&
                          block == (unsigned)trpx::kBlock;
-    // many small frames: one workgroup per frame, the walk and the extraction overlap inside it;
-    // few large frames: the tiled kernels (the walk is then the whole critical path either way)
+    // frames whose worst case fits 2^26 bits: one workgroup per frame, the walk and the extraction overlap inside it -- whatever
+    // the number of frames (since the round-3 walker a single 512^2 frame takes 0.10 ms this way against 0.24 ms through the
+    // position-parallel walk + tiled extraction, eight 1024^2 frames 0.37 against 0.73 ms); larger frames: the tiled kernels
     // (the per-frame decoder packs a block's bit position with its width into 32 bits: frames of < 2^26 bits less the
     // walker's ring offset and one step's overshoot)
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
-    if (fast_ok && frame26 && !force_tiles && (force_frames || n_frames >= 128))
+    if (fast_ok && frame26 && !force_tiles)
         HIP_TRY(trpx::launch_decode_frames(out_dtype, a, static_cast<hipStream_t>(stream)));
     else if (fast_ok)
         HIP_TRY(trpx::launch_decode_fast(out_dtype, a, false, static_cast<hipStream_t>(stream)));
@@ -325,9 +326,8 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     a.widths = reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths);
     a.seg_ws = static_cast<char*>(index) + il.seg;
     a.defer = reinterpret_cast<uint32_t*>(static_cast<char*>(index) + il.defer);
-    // many small frames: the per-frame decoder's walker writes the index (the conditions of trpx_decode's per-frame route)
-    a.index_per_frame = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) + (1u << 17) < (1ull << 26) && g_decode_path != 2 &&
-                        (g_decode_path == 3 || n_frames >= 128);
+    // frames of < 2^26 bits: the per-frame decoder's walker writes the index (the conditions of trpx_decode's per-frame route)
+    a.index_per_frame = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) + (1u << 17) < (1ull << 26) && g_decode_path != 2;
     HIP_TRY(trpx::launch_walk_only(a, (uint32_t)(8 * trpx_dtype_size(dtype)), clear_status, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }
@@ -364,7 +364,7 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     a.status = status;
     a.tile_off = reinterpret_cast<uint64_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.group_off);
     a.widths = reinterpret_cast<uint8_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.widths);
-    // many small frames: one workgroup per frame (the conditions of trpx_decode's per-frame route), else the tiled kernel
+    // many small frames: one workgroup per frame; few frames: the tiled kernel spreads a frame's tiles over the whole GPU
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
     const bool per_frame = frame26 && g_decode_path != 2 && (g_decode_path == 3 || n_frames >= 128);
     HIP_TRY(trpx::launch_decode_fast(out_dtype, a, true, static_cast<hipStream_t>(stream), per_frame));
