@@ -190,7 +190,7 @@ int trpx_set_encode_path(int path);
  * vector-aligned frames of < 2^26 bits, the position-parallel walk + tiled extraction for larger frames, the
  * basic kernels for unaligned frames, other block sizes and missing frame offsets), 1 = always the basic kernels, 2 = the
  * tiled route whenever its preconditions hold, 3 = the per-frame decoder whenever its preconditions hold (= auto for
- * trpx_decode; trpx_decode_indexed then also uses it for fewer than 128 frames).  Every route yields the same pixels (Terse.hpp:352-389); the setter exists for tests and A/B measurements.
+ * trpx_decode; trpx_decode_indexed, which takes it from 1024 frames on, then uses it for any number).  Every route yields the same pixels (Terse.hpp:352-389); the setter exists for tests and A/B measurements.
  * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames.
  * These two variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
  */

@@ -364,9 +364,11 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     a.status = status;
     a.tile_off = reinterpret_cast<uint64_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.group_off);
     a.widths = reinterpret_cast<uint8_t*>(const_cast<char*>(static_cast<const char*>(index)) + il.widths);
-    // many small frames: one workgroup per frame; few frames: the tiled kernel spreads a frame's tiles over the whole GPU
+    // a thousand frames and more: one workgroup per frame; fewer: the tiled kernel spreads a frame's tiles over the whole GPU
+    // (512^2 u16 frames, tiled / per-frame: 128 frames 0.023 / 0.121 ms, 600 frames 0.092 / 0.137, 1000 frames 0.148 / 0.142, 2000
+    // frames 0.30 / 0.21 -- both scale with the blocks per frame, so the frame count alone decides)
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
-    const bool per_frame = frame26 && g_decode_path != 2 && (g_decode_path == 3 || n_frames >= 128);
+    const bool per_frame = frame26 && g_decode_path != 2 && (g_decode_path == 3 || n_frames >= 1024);
     HIP_TRY(trpx::launch_decode_fast(out_dtype, a, true, static_cast<hipStream_t>(stream), per_frame));
     return TRPX_OK;
 }
