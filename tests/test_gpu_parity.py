@@ -1068,7 +1068,7 @@ def _fuzz_stack(rng, dt, kind, n, frames):
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_build_index_of_many_small_frames(gpu, oracle, dtype):
-    """trpx_build_index on a stack of >= 128 small frames runs the per-frame walker with index writers in place of the extraction
+    """trpx_build_index on a stack of frames of < 2^26 bits runs the per-frame walker with index writers in place of the extraction
     (k_index_frames; header-dense frames go to the position-parallel walk): the index must equal the one the encoder writes as a
     by-product, block for block and group for group, and decode the stack (Terse.hpp:360-372 has one chain per frame)."""
     import torch
@@ -1077,7 +1077,8 @@ def test_build_index_of_many_small_frames(gpu, oracle, dtype):
     tdt = {1: torch.uint8 if dt.kind == "u" else torch.int8, 2: torch.uint16 if dt.kind == "u" else torch.int16,
            4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
     rng = np.random.RandomState(4242 + ALL_DTYPES.index(dtype))
-    for kind, n, frames in ((2, 40000, 130), (3, 12 * 1024 + 8, 140), (1, 3000, 200), (5, 50000, 131), (0, 52, 129)):
+    for kind, n, frames in ((2, 40000, 130), (3, 12 * 1024 + 8, 140), (1, 3000, 200), (5, 50000, 131), (0, 52, 129),
+                            (3, 12 * 34000, 4), (2, 12 * 34000 + 4, 3)):          # (> 32 K blocks: dense frames go through several wavefronts each)
         px = _fuzz_stack(rng, dt, kind, n, frames)
         dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
         enc = codec.encode(dpx, index=True)
@@ -1109,7 +1110,8 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
            4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
     rng = np.random.RandomState(1000 * _ROUTES[route] + ALL_DTYPES.index(dtype))
     cases = [(0, 4096, 3), (1, 12 * 768 + 4, 17), (2, 40000, 130), (3, 3000, 140), (4, 131072, 3), (2, 388, 129), (1, 52, 2),
-             (5, 50000, 131), (5, 262144, 4), (2, 12 * 40000 + 8, 3)]      # (the last one: > 32 K blocks, several wavefronts per frame on the tiled route)
+             (5, 50000, 131), (5, 262144, 4), (2, 12 * 40000 + 8, 3),      # (> 32 K blocks: several wavefronts per frame on the tiled route,
+             (3, 12 * 34000, 5)]                                            #  and the per-frame decoder's hand-over of dense frames through them)
     assert L.trpx_set_decode_path(9) != 0                                    # out of range: refused
     try:
         assert L.trpx_set_decode_path(_ROUTES[route]) == 0

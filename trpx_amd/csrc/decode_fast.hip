@@ -33,10 +33,14 @@ __global__ __launch_bounds__(kWave) void k_walk_lds(const uint8_t* __restrict__ 
                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                     uint32_t max_w, uint8_t* __restrict__ widths,
                                                     uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ only,
-                                                    uint32_t* __restrict__ status) {
+                                                    const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     __shared__ uint32_t s_chunk[kWalkChunkDw + 4];
     const uint32_t lane = (uint32_t)lane_id();
-    const uint64_t frame = blockIdx.x;
+    uint64_t frame = blockIdx.x;
+    if (list) {                                       // (the frames k_decode_frames listed, see decode_seg.hip)
+        if (blockIdx.x >= list[0]) return;
+        frame = list[1u + blockIdx.x] & 0x7FFFFFFFu;
+    }
     if (only && !only[frame]) return;                 // (frames the position-parallel walk has done)
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     if (!(fe > fo && fe <= terse_bytes)) {
@@ -322,7 +326,7 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, boo
     return hipGetLastError();
 }
 
-hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st);
+hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st, const uint32_t* list = nullptr);
 
 // Fast path preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned.
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
@@ -335,15 +339,15 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
 #else
     constexpr bool lds_walk = false;
 #endif
-    if (!lds_walk && a.seg_ws && a.index_per_frame && a.defer && seg_single_wave(a.geom))
+    if (!lds_walk && a.seg_ws && a.index_per_frame && a.defer)
         return launch_index_frames(max_w, a, false, st);        // (status cleared above if asked)
     if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, st);
     return launch_walk_lds_only(a, max_w, nullptr, st);
 }
 
-hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st) {
+hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st, const uint32_t* list) {
     hipLaunchKernelGGL(k_walk_lds, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                       a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, only, a.status);
+                       a.frame_offsets, a.geom, max_w, a.widths, a.tile_off, only, list, a.status);
     return hipGetLastError();
 }
 

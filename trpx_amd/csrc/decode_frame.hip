@@ -675,7 +675,7 @@ hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const ui
 
 template <typename T>
 static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
-    uint32_t* defer = a.defer && a.seg_ws && seg_single_wave(a.geom) ? a.defer : nullptr;
+    uint32_t* defer = a.defer && a.seg_ws ? a.defer : nullptr;
     hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(defer), (uint64_t)(defer ? 1 : 0),
                        reinterpret_cast<uint64_t*>(a.status), (uint64_t)4);   // status block + the deferred-frame count
     Profiler& prof = profiler();

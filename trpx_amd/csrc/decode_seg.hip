@@ -753,13 +753,54 @@ hipError_t launch_seg_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t
     return hipGetLastError();
 }
 
+// Tiles of the listed frames of more than 32 K blocks, after launch_seg_multi has written their index: a fixed grid strides over
+// (listed frame, tile) pairs.  (Frames of one wavefront's worth go back to the per-frame decoder with the widths given -- 0.20
+// against 0.31 ms for 2000 listed 512^2 frames --; a large frame is the other way round: its extraction by one workgroup's three
+// waves is a 0.45 ms chain of 455 groups for 1024^2 pixels, its tiles spread over the GPU take 0.05 ms.)
+template <typename T>
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 5) void k_unpack_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               const uint8_t* __restrict__ widths,
+                                                               const uint64_t* __restrict__ tile_off,
+                                                               const uint32_t* __restrict__ list, T* __restrict__ pixels_out,
+                                                               uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_image[unpack_image_dwords<T>()];
+    __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[unpack_stage_dwords<T>()];
+    const uint32_t count = list[0];
+    if (count == 0u || status[0] != 0u) return;
+    constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
+    const uint32_t tpf = (g.n_blocks + tb - 1) / tb;
+    const uint64_t total = (uint64_t)count * tpf;
+    for (uint64_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const uint32_t frame = list[1 + (uint32_t)(i / tpf)] & 0x7FFFFFFFu;
+        if (!unpack_tile<T>(terse, terse_bytes, frame_offsets, g, frame, (uint32_t)(i % tpf), widths, tile_off, pixels_out, status,
+                            s_image, s_wtot, s_stage))
+            return;
+        __syncthreads();
+    }
+}
+
+// A frame of the launch: slot itself, or -- list given (the frames k_decode_frames listed) -- list[1 + slot] (bit 31: header-dense,
+// see k_seg_listed); false: the slot is behind the list's end.
+__device__ __forceinline__ bool seg_listed_frame(const uint32_t* __restrict__ list, uint64_t slot, uint64_t& frame, bool& run_guess) {
+    frame = slot; run_guess = true;
+    if (!list) return true;
+    if (slot >= list[0]) return false;
+    const uint32_t e = list[1u + slot];
+    frame = e & 0x7FFFFFFFu; run_guess = (e >> 31) == 0u;
+    return true;
+}
+
 // ---- several wavefronts per frame (large frames): rounds / resolve / write are separate launches -------------------------
 __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
                                                      uint32_t K, uint32_t first, SegWs ws, uint8_t* __restrict__ widths,
-                                                     uint32_t* __restrict__ status) {
+                                                     const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
-    const uint64_t frame = blockIdx.x / K;
+    uint64_t frame;
+    bool run_guess;
+    if (!seg_listed_frame(list, blockIdx.x / K, frame, run_guess)) return;
     const uint32_t k = blockIdx.x % K;
     SegCtx c;
     if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave, status)) {
@@ -774,7 +815,7 @@ __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__
 #endif
     // (the first launch, where no wavefront but the frame's first knows its lane 0 is right, stops after 4 rounds: what is open then
     // closes faster with the links of the second launch -- 2 / 3 / 4 / 6 / 8 / 12 rounds: 0.58 / 0.59 / 0.46 / 0.50 / 0.50 / 0.54 ms)
-    seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, first ? 4 : 12, seg_state(ws, frame, K));
+    seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, first ? 4 : 12, seg_state(ws, frame, K), run_guess);
 #ifdef TRPX_SEG_STAMPS
     if (first && threadIdx.x == 0) {                            // tools/c4_time.py (SEG_PER_WAVE=1): status block of 16 + 8 * waves words
         uint32_t* o = status + 16 + 8 * blockIdx.x;
@@ -789,9 +830,12 @@ __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__
 // A frame with too many open waves is left to the serial walk (fallback flag).
 __global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                        const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                       uint32_t K, SegWs ws, uint32_t* __restrict__ status) {
+                                                       uint32_t K, SegWs ws, const uint32_t* __restrict__ list,
+                                                       uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
-    const uint64_t frame = blockIdx.x;
+    uint64_t frame;
+    bool run_guess;
+    if (!seg_listed_frame(list, blockIdx.x, frame, run_guess)) return;
     const uint32_t lane = (uint32_t)lane_id();
     if (lane == 0) ws.fallback[frame] = 0u;
     SegCtx c;
@@ -835,9 +879,12 @@ __global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict
 __global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                      const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
                                                      uint32_t K, SegWs ws, uint8_t* __restrict__ widths,
-                                                     uint64_t* __restrict__ tile_off, uint32_t* __restrict__ status) {
+                                                     uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ list,
+                                                     uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
-    const uint64_t frame = blockIdx.x / K;
+    uint64_t frame;
+    bool run_guess;
+    if (!seg_listed_frame(list, blockIdx.x / K, frame, run_guess)) return;
     const uint32_t k = blockIdx.x % K;
     const uint32_t lane = (uint32_t)lane_id();
     if (ws.fallback[frame]) return;                            // the serial walk does this frame
@@ -873,36 +920,45 @@ size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     return align_up(segs * (8 + 8 + 4 + 4) + n_frames * K * 12 + n_frames * 4, 256);
 }
 
-hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st);   // decode_fast.hip
+hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st, const uint32_t* list = nullptr);   // decode_fast.hip
 
 // Fills a.widths / a.tile_off (the decode index) from the stream.
+// Several wavefronts per frame: every frame of the stack (list == nullptr) or the frames of a list.
+static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t K, const uint32_t* list, hipStream_t st) {
+    const SegWs ws = seg_carve(a.seg_ws, a.n_frames, K);
+    const dim3 grid((uint32_t)((size_t)a.n_frames * K));
+    hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                       K, 1u, ws, a.widths, list, a.status);
+    hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                       K, 0u, ws, a.widths, list, a.status);
+    // (a third launch: what it leaves open, k_seg_resolve closes one wavefront at a time -- 0.22 ms for eight 4096^2 frames after
+    // two launches, 0.02 ms after three, which cost 0.14 ms)
+    hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                       K, 0u, ws, a.widths, list, a.status);
+    hipLaunchKernelGGL(k_seg_resolve, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
+                       a.geom, max_w, K, ws, list, a.status);
+    hipLaunchKernelGGL(k_seg_write, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                       K, ws, a.widths, a.tile_off, list, a.status);
+    return launch_walk_lds_only(a, max_w, ws.fallback, st, list);    // frames that did not converge: the serial walk
+}
+
 hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
     const uint32_t K = seg_waves_per_frame(a.geom);
-    const SegWs ws = seg_carve(a.seg_ws, a.n_frames, K);
     if (K == 1) {
+        const SegWs ws = seg_carve(a.seg_ws, a.n_frames, K);
         hipLaunchKernelGGL(k_seg_frames, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
                            a.geom, max_w, ws, a.widths, a.tile_off, a.status);
         return hipGetLastError();
     }
-    const dim3 grid((uint32_t)((size_t)a.n_frames * K));
-    hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, 1u, ws, a.widths, a.status);
-    hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, 0u, ws, a.widths, a.status);
-    // (a third launch: what it leaves open, k_seg_resolve closes one wavefront at a time -- 0.22 ms for eight 4096^2 frames after
-    // two launches, 0.02 ms after three, which cost 0.14 ms)
-    hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, 0u, ws, a.widths, a.status);
-    hipLaunchKernelGGL(k_seg_resolve, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
-                       a.geom, max_w, K, ws, a.status);
-    hipLaunchKernelGGL(k_seg_write, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
-                       K, ws, a.widths, a.tile_off, a.status);
-    return launch_walk_lds_only(a, max_w, ws.fallback, st);    // frames that did not converge: the serial walk
+    return launch_seg_multi(a, max_w, K, nullptr, st);
 }
 
 
-// The decode index of the frames listed in a.defer (one wavefront per listed frame; needs seg_single_wave(a.geom)).
+// The decode index of the frames listed in a.defer: one wavefront per listed frame, or the launches of launch_seg_multi for
+// frames of more than 32 K blocks.
 hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
+    const uint32_t K = seg_waves_per_frame(a.geom);
+    if (K > 1) return launch_seg_multi(a, max_w, K, static_cast<const uint32_t*>(a.defer), st);
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
     hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
                        a.geom, max_w, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
@@ -913,6 +969,14 @@ template <typename T>
 static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
     const hipError_t e0 = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
     if (e0 != hipSuccess) return e0;
+    if (seg_waves_per_frame(a.geom) > 1u) {                     // large frames: their tiles, spread over the GPU
+        constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
+        const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);
+        hipLaunchKernelGGL((k_unpack_listed<T>), dim3((uint32_t)(tiles < 1024 ? tiles : 1024)), dim3(kThreads), 0, st, a.terse,
+                           (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer),
+                           static_cast<T*>(a.pixels_out), a.status);
+        return hipGetLastError();
+    }
     // the listed frames' pixels: the per-frame decoder again, with the widths just written in place of its walker
     constexpr int dtype = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
                           : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2) : (PixelTraits<T>::is_signed ? 5 : 4);
