@@ -79,7 +79,8 @@ size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, 
  * push_back (Terse.hpp:263-270, :290-302, :500-549) and the Bit_range::append_range /
  * operator|= / Bit::set primitives under it (Bit_pointer.hpp:700-730, :628-649, :490).
  *
- *   pixels        DEVICE  const T[n_frames * n_values], 16-byte aligned
+ *   pixels        DEVICE  const T[n_frames * n_values], aligned to T (16-byte aligned with n_values % 4 == 0 is the fastest case:
+ *                           every vector access then stays inside aligned lines; any n_values runs on the same kernels)
  *   out           DEVICE  uint8_t[out_capacity], 16-byte aligned; receives sum(S_f) bytes
  *   frame_offsets DEVICE  uint64_t[n_frames + 1]; [k] = first byte of frame k, [n_frames] = total
  *   status        DEVICE  uint32_t[TRPX_STATUS_WORDS], 8-byte aligned (see above); word 1 = prolix_bits
@@ -104,7 +105,7 @@ int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames,
  *   terse          DEVICE const uint8_t[terse_bytes], 4-byte aligned
  *   frame_offsets  DEVICE const uint64_t[n_frames + 1], or NULL: the frames are then located by
  *                  a serial header walk on the device (the .trpx format stores no index)
- *   pixels_out     DEVICE T[n_frames * n_values], 16-byte aligned
+ *   pixels_out     DEVICE T[n_frames * n_values], aligned to T (16-byte aligned with n_values % 4 == 0: the fastest case)
  *   status         DEVICE uint32_t[TRPX_STATUS_WORDS]; word 0 = TRPX_ERR_CORRUPT if a frame's
  *                  bits run past its end (the reference does not check; we do)
  */
@@ -179,8 +180,7 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
                     void* pixels_dev, void* stream);
 
 /*
- * Encoder selection: 0 = auto (default: the single-pass look-back encoder whenever n_values % 4 == 0
- * and `pixels` is 16-byte aligned, else the two-pass pipeline), 1 = always the two-pass pipeline.
+ * Encoder selection: 0 = auto (default: the single-pass look-back encoder), 1 = always the two-pass pipeline.
  * Process-wide; also settable with the environment variable TRPX_ENCODE_PATH=twopass.
  */
 int trpx_set_encode_path(int path);

@@ -97,21 +97,25 @@ def test_differential_vs_oracle_all_dtypes(gpu, oracle, dtype):
 
 def test_type_extremes_round_trip(gpu, oracle):
     # outside the reference's validity domain (D3): oracle == GPU == mathematically consistent extension
+    # (42 values: a partial last block of 6; 48 and 4800: whole blocks -- -INT32_MIN once overflowed in the single-pass encoder's
+    #  width computation and came out as a 33-bit block, which the 42-value case never saw while sizes that are no multiples
+    #  of 4 still took the two-pass pipeline)
     for dt in (np.int16, np.int32, np.int8):
         info = np.iinfo(dt)
-        px = np.array([info.min, info.max, -1, 0, 1, info.min + 1] * 7, dt).reshape(1, -1)
-        want, sizes, pb = oracle.encode_stack(px)
-        got, offs, gpb = _host_encode(px)
-        assert (got == want).all() and gpb == pb == info.bits
-        assert (_host_decode(got, offs, px.shape[1], 1, dt) == px).all()
+        for reps in (7, 8, 800):
+            px = np.array([info.min, info.max, -1, 0, 1, info.min + 1] * reps, dt).reshape(1, -1)
+            want, sizes, pb = oracle.encode_stack(px)
+            got, offs, gpb = _host_encode(px)
+            assert (got == want).all() and gpb == pb == info.bits, (dt, reps)
+            assert (_host_decode(got, offs, px.shape[1], 1, dt) == px).all(), (dt, reps)
     px = np.array([0xFFFFFFFF, 0x80000000, 1, 0] * 5, np.uint32).reshape(1, -1)
     got, offs, gpb = _host_encode(px)
     assert gpb == 32 and (got == oracle.encode_stack(px)[0]).all()
     assert (_host_decode(got, offs, px.shape[1], 1, np.uint32) == px).all()
 
 
-def test_unaligned_frame_sizes_take_the_scalar_path(gpu, oracle):
-    # n % 4 != 0 -> frames are not vector aligned
+def test_frame_sizes_that_are_no_multiples_of_four(gpu, oracle):
+    # n % 4 != 0 -> frames start at any element; since round 3 they run on the tuned kernels too (the route matrix forces the others)
     rng = np.random.RandomState(3)
     for n in (13, 4097, 10001):
         px = rng.poisson(5, size=(4, n)).astype(np.uint16)
@@ -1078,7 +1082,8 @@ def test_build_index_of_many_small_frames(gpu, oracle, dtype):
            4: torch.uint32 if dt.kind == "u" else torch.int32}[dt.itemsize]
     rng = np.random.RandomState(4242 + ALL_DTYPES.index(dtype))
     for kind, n, frames in ((2, 40000, 130), (3, 12 * 1024 + 8, 140), (1, 3000, 200), (5, 50000, 131), (0, 52, 129),
-                            (3, 12 * 34000, 4), (2, 12 * 34000 + 4, 3)):          # (> 32 K blocks: dense frames go through several wavefronts each)
+                            (3, 12 * 34000, 4), (2, 12 * 34000 + 4, 3),           # (> 32 K blocks: dense frames go through several wavefronts each)
+                            (2, 513 * 7, 131), (3, 1030 * 53 + 1, 3)):            # (no multiples of 4)
         px = _fuzz_stack(rng, dt, kind, n, frames)
         dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
         enc = codec.encode(dpx, index=True)
@@ -1111,7 +1116,9 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
     rng = np.random.RandomState(1000 * _ROUTES[route] + ALL_DTYPES.index(dtype))
     cases = [(0, 4096, 3), (1, 12 * 768 + 4, 17), (2, 40000, 130), (3, 3000, 140), (4, 131072, 3), (2, 388, 129), (1, 52, 2),
              (5, 50000, 131), (5, 262144, 4), (2, 12 * 40000 + 8, 3),      # (> 32 K blocks: several wavefronts per frame on the tiled route,
-             (3, 12 * 34000, 5)]                                            #  and the per-frame decoder's hand-over of dense frames through them)
+             (3, 12 * 34000, 5),                                            #  and the per-frame decoder's hand-over of dense frames through them)
+             (2, 12 * 300 + 7, 130), (1, 2463 * 3, 4), (3, 1030 * 53 + 1, 3), (2, 12 * 34000 + 3, 3)]   # pixel counts that are no multiples of 4:
+    #                                                                            frames start at any element (1030 x 1065, 2463 x 2527 detectors)
     assert L.trpx_set_decode_path(9) != 0                                    # out of range: refused
     try:
         assert L.trpx_set_decode_path(_ROUTES[route]) == 0
@@ -1119,7 +1126,7 @@ def test_decode_route_matrix(gpu, oracle, route, dtype):
             px = _fuzz_stack(rng, dt, kind, n, frames)
             want, sizes, pb = oracle.encode_stack(px)
             dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).to(gpu).view(tdt)
-            enc = codec.encode(dpx, index=n % 4 == 0)
+            enc = codec.encode(dpx, index=True)
             torch.cuda.synchronize()
             enc.check()
             assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb, ("encode", route, dtype, kind, n, frames)

@@ -72,7 +72,7 @@ EncWs enc_ws(const trpx::FrameGeom& g, size_t n_frames) {
     return w;
 }
 
-// 0 = auto (single-pass encoder when the frames are vector aligned), 1 = force the two-pass pipeline.
+// 0 = auto (single-pass encoder), 1 = force the two-pass pipeline.
 // Initialised from $TRPX_ENCODE_PATH ("twopass" / "fused"), changed by trpx_set_encode_path().
 int g_encode_path = [] {
     const char* e = getenv("TRPX_ENCODE_PATH");
@@ -208,8 +208,9 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
         HIP_TRY(trpx::launch_encode_generic(dtype, a, static_cast<hipStream_t>(stream)));
         return TRPX_OK;
     }
-    const bool vec_ok = n_values % 4 == 0 && (uintptr_t)pixels % 16 == 0 &&
-                        (uint64_t)g.n_blocks * 396 < (1ull << 40);       // frame bits fit the fused encoder's 40-bit accumulator
+    // (frames need not be vector aligned -- most detectors' pixel counts are not multiples of 4: 1030 x 1065, 2463 x 2527 --: the
+    // kernels' 16-byte accesses only need what the hardware needs, which in HSA's unaligned access mode is nothing)
+    const bool vec_ok = (uint64_t)g.n_blocks * 396 < (1ull << 40);       // frame bits fit the fused encoder's 40-bit accumulator
     if (g_encode_path == 0 && !t_force_two_pass && vec_ok)
         HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
     else {
@@ -284,8 +285,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     const int route = g_decode_path;                                          // trpx_set_decode_path / $TRPX_DECODE_PATH
     const bool basic = route == 1, force_tiles = route == 2;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
-    const bool fast_ok = frame_offsets && !basic && bits32 && n_values % 4 == 0 && (uintptr_t)pixels_out % 16 == 0 &&
-                         block == (unsigned)trpx::kBlock;
+    const bool fast_ok = frame_offsets && !basic && bits32 && block == (unsigned)trpx::kBlock;
     // frames whose worst case fits 2^26 bits: one workgroup per frame, the walk and the extraction overlap inside it -- whatever
     // the number of frames (since the round-3 walker a single 512^2 frame takes 0.10 ms this way against 0.24 ms through the
     // position-parallel walk + tiled extraction, eight 1024^2 frames 0.37 against 0.73 ms); larger frames: the tiled kernels
@@ -350,9 +350,9 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: bad sizes");
     if (!terse || !pixels_out || !status || !index || !frame_offsets)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: null pointer");
-    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 || (uintptr_t)pixels_out % 16 ||
-        (uintptr_t)status % 8 || n_values % 4)
-        return fail(TRPX_ERR_UNSUPPORTED, "trpx_decode_indexed: needs n_values %% 4 == 0, 16-byte aligned pixels_out/index");
+    if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 ||
+        (uintptr_t)pixels_out % trpx_dtype_size(out_dtype) || (uintptr_t)status % 8)
+        return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: misaligned pointer (terse needs 4 B, index 16 B)");
     const IdxLayout il = idx_layout(g, n_frames);
     trpx::DecodeArgs a{};
     a.terse = terse;
@@ -737,12 +737,12 @@ int trpx_group_states_host(const uint8_t* terse, size_t terse_bytes, const uint6
 int trpx_decode_host_grouped(int stream_signed, int out_dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
                              const uint64_t* group_states, size_t n_values, size_t n_frames, unsigned block, void* pixels_out,
                              int device) {
-    // the tuned, walk-free route needs a same-signedness integer type and vector-aligned frames; everything else (and a
+    // the tuned, walk-free route needs a same-signedness integer type; everything else (and a
     // state table that does not fit the stream) goes the general way
     trpx::FrameGeom g;
     const bool tuned = group_states && frame_offsets && out_dtype <= TRPX_I32 && trpx_dtype_size(out_dtype) &&
                        (stream_signed != 0) == (trpx_dtype_is_signed(out_dtype) != 0) && block == (unsigned)trpx::kBlock &&
-                       n_values % 4 == 0 && geom_of(n_values, block, &g) && sizes_ok(g, n_frames);
+                       geom_of(n_values, block, &g) && sizes_ok(g, n_frames);
     if (!tuned) return trpx_decode_host(stream_signed, out_dtype, terse, terse_bytes, frame_offsets, n_values, n_frames, block, pixels_out, device);
     if (trpx_device_count() == 0) return fail(TRPX_ERR_NO_DEVICE, "trpx_decode_host_grouped: no HIP device");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
@@ -842,7 +842,7 @@ int trpx_stack_open(trpx_stack** handle, int stream_signed, const uint8_t* terse
     if ((e = hipMemsetAsync(s->d_terse, 0, trpx::align_up(terse_bytes, 4) + 8, hs)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = copy_sync(hs, s->d_terse, terse, terse_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(stack)");
     if ((e = copy_sync(hs, s->d_offs, s->offs.data(), 8 * (n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(offsets)");
-    if (group_states && block == (unsigned)trpx::kBlock && n_values % 4 == 0) {   // row f1: the file carried its group states
+    if (group_states && block == (unsigned)trpx::kBlock) {   // row f1: the file carried its group states
         s->groups = g.n_tiles;
         if ((e = hipMalloc(&s->d_states, 8 * n_frames * s->groups)) != hipSuccess) return bail(e, "hipMalloc(states)");
         if ((e = copy_sync(hs, s->d_states, group_states, 8 * n_frames * s->groups, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(states)");

@@ -272,7 +272,10 @@ __device__ __forceinline__ uint32_t raw_width(const uint32_t (&raw)[Raw<T>::dw])
         if (bits == 8) { m |= m >> 16; m = (m | (m >> 8)) & 0xFFu; }
     } else if (bits == 32) {
 #pragma unroll
-        for (int i = 0; i < Raw<T>::dw; ++i) { const int32_t x = (int32_t)raw[i]; m |= (uint32_t)(x < 0 ? -x : x); }
+        for (int i = 0; i < Raw<T>::dw; ++i) {                           // |x| in unsigned arithmetic: -INT32_MIN overflows as an int,
+            const uint32_t u = raw[i];                                  // and a compiler that may assume it does not drops the clamp
+            m |= (int32_t)u < 0 ? 0u - u : u;                           // of width_from_or (33-bit widths for blocks that hold INT32_MIN)
+        }
     } else if (bits == 16) {
         typedef short s2 __attribute__((ext_vector_type(2)));
         uint32_t acc = 0;
