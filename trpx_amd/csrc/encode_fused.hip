@@ -278,12 +278,14 @@ __device__ __forceinline__ uint32_t raw_width(const uint32_t (&raw)[Raw<T>::dw])
         }
     } else if (bits == 16) {
         typedef short s2 __attribute__((ext_vector_type(2)));
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         uint32_t acc = 0;
 #pragma unroll
-        for (int i = 0; i < Raw<T>::dw; ++i) {                          // packed |x| = max(x, -x) (wraps for -32768)
-            union { uint32_t u; s2 v; } x, y;
+        for (int i = 0; i < Raw<T>::dw; ++i) {                          // packed |x| = max(x, -x); the negation in unsigned arithmetic
+            union { uint32_t u; s2 v; us2 w; } x, n, y;                 // (-(-32768) wraps to -32768 by definition, not by luck)
             x.u = raw[i];
-            y.v = __builtin_elementwise_max(x.v, (s2)(-x.v));
+            n.w = (us2)(0) - x.w;
+            y.v = __builtin_elementwise_max(x.v, n.v);
             acc |= y.u;
         }
         m = (acc | (acc >> 16)) & 0xFFFFu;                              // |−32768| reads 0x8000: bitlen 16 -> clamped below
