@@ -14,7 +14,7 @@ t0 = time.time()
 for c in range(cases):
     dt = np.dtype(DT[rng.randint(6)])
     top = 8 * dt.itemsize - (2 if dt.kind == "i" else (1 if dt.itemsize == 4 else 0))      # inside the reference's validity domain (D3)
-    n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3)]))
+    n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3), 12 * 34000 + 8 * rng.randint(0, 3)]))
     n = max(1, n - rng.randint(0, 4) * rng.randint(0, 2))                                     # (half of the cases: no multiple of 4)
     frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else int(rng.choice([1, 3, 130]))
     nblk = (n + 11) // 12
