@@ -190,7 +190,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #pragma unroll
                 for (int i = 0; i < kChunks; ++i) {
                     const uint32_t b0 = beg_b + (uint32_t)i * kWave;
-                    if (b0 >= end_nom) break;                                         // (wave-uniform)
+                    if (b0 >= end_nom) continue;                                      // (wave-uniform; no break: the loop has to unroll, wq[] lives in registers)
                     const uint32_t bi = b0 + lane, wi = wq[i];
                     uint32_t wp = (uint32_t)__shfl_up((int)wi, 1, 64);
                     if (lane == 0) wp = w_prev;
