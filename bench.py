@@ -33,7 +33,7 @@ FRAMES_PER_GPU = 2000
 ENC_STAGES_TWOPASS = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
 ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
 DEC_STAGES = ["walk", "unpack"]        # tiled decode (two kernels)
-PROFILE_TAG = "r03"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
+PROFILE_TAG = "r04"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
 DEC_STAGES_FRAMES = ["decode_frames", "deferred_frames"]  # one workgroup per frame (walk + extraction fused) + the frames it defers
 
 
@@ -393,6 +393,9 @@ def main():
                   "encode_fps": f4 / t_e * 1e3, "encode_pixel_GBps": f4 * n4 * 4 / t_e / 1e6,
                   "decode_fps": f4 / t_p * 1e3, "decode_pixel_GBps": f4 * n4 * 4 / t_p / 1e6,
                   "decode_with_index_fps": f4 / t_d * 1e3, "decode_with_index_pixel_GBps": f4 * n4 * 4 / t_d / 1e6,
+                  "encode_ms": t_e, "decode_ms": t_p, "decode_with_index_ms": t_d, "algorithmic_bytes": alg4,
+                  "decode_frac_of_hbm_peak": alg4 / t_p / 1e6 / HBM_PEAK_GBPS,
+                  "decode_with_index_frac_of_hbm_peak": alg4 / t_d / 1e6 / HBM_PEAK_GBPS,
                   "kernel_ms": st4,
                   "roofline_encode": {"bound": "hbm", "kernel": "k_encode_fused<int32_t>", "achieved": alg4 / st4["encode_fused"] / 1e6,
                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg4 / st4["encode_fused"] / 1e6 / HBM_PEAK_GBPS,
@@ -402,37 +405,98 @@ def main():
         except Exception as ex:      # informative leg only
             c4 = {"error": repr(ex)}
 
-        # noisy_u16 (informative): detector-like counts whose block width flips between 2 and 3 bits from block to block
-        # (Poisson(1.5) background clamped to 0..6 + 1/4096 peaks < 4000, the generator of tools/dtype_time.py): an explicit
-        # header every other block -- the worst case for the header chain (Terse.hpp:360-372), unlike synth-v1
-        noisy = {}
-        try:
+        # ---- measured memory ceilings of THIS box (SURVEY.md 8 row d: fraction of nominal AND of measured-achievable) ----
+        def stream_GBps(mode, nbytes):
+            src = px.view(torch.uint8).reshape(-1)[:nbytes]
+            dst = back.view(torch.uint8).reshape(-1)[:nbytes]
+            sink = st_d if mode == 0 else dst
+            s_ = torch.cuda.current_stream().cuda_stream
+            ms = timed(lambda: _lib.check(L.trpx_bench_stream(mode, src.data_ptr(), sink.data_ptr(), nbytes, s_)), 10)
+            return (2 if mode == 2 else 1) * nbytes / ms / 1e6
+        measured = {"read_GBps": stream_GBps(0, pix_bytes), "write_GBps": stream_GBps(1, pix_bytes), "copy_GBps": stream_GBps(2, pix_bytes),
+                    "how": "trpx_bench_stream: grid-stride 16 B/lane non-temporal kernels over the stack's pixel bytes, HIP events, 10 launches"}
+        # (what the decoder left in `back` was overwritten: restore the headline result for the checks below)
+        codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+        for r_, kind in ((roofs.get("encode"), "read"), (roofs.get("decode"), "write")):
+            if r_:
+                r_["peak_measured"] = measured[kind + "_GBps"]
+                r_["peak_measured_kind"] = f"{kind} stream ({'pixel loads' if kind == 'read' else 'pixel stores'} are 84 % of this kernel's bytes)"
+                r_["frac_of_measured"] = r_["achieved"] / measured[kind + "_GBps"]
+
+        # ---- informative legs (not part of `value`): the workloads the headline stack hides ---------------------------------
+        # Each leg: encode, index-free decode, decode with the encoder's decode index, per-kernel HIP-event times, frame 0
+        # byte-identical to the CPU oracle, every frame round-trips.  Fractions are of the 8 TB/s nominal peak on ALGORITHMIC
+        # bytes (pixels + stream), SURVEY.md 8d.
+        def leg(pxl, what):
+            nf, nv = pxl.shape[0], pxl[0].numel()
+            bk = torch.empty_like(pxl)
+            en = codec.encode(pxl, out=out, workspace=ws, frame_offsets=offs[: nf + 1], status=st_e)
+            torch.cuda.synchronize()
+            en.check()
+            nbytes = en.total_bytes()
+            want = O.encode(pxl[0].cpu().numpy().reshape(-1))[0]
+            assert (out[: want.size].cpu().numpy() == want).all(), f"{what}: frame 0 differs from the CPU oracle"
+            fo = offs[: nf + 1]
+            t_e = timed(lambda: codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e))
+            t_d = timed(lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws, status=st_d))
+            assert int(st_d[0].item()) == 0 and torch.equal(bk.view(torch.int16), pxl.view(torch.int16)), f"{what}: round trip differs"
+            bk.zero_()
+            en_i = codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e, index=True)
+            t_i = timed(lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, status=st_d, index=en_i.index))
+            assert int(st_d[0].item()) == 0 and torch.equal(bk.view(torch.int16), pxl.view(torch.int16)), f"{what}: indexed decode differs"
+            km = stages(lambda: codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e),
+                        lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws, status=st_d), DEC_STAGES_FRAMES, 5)
+            pb = nf * nv * 2
+            alg = pb + nbytes
+            return {"workload": what, "frames": nf, "n_values": nv,
+                    "encode_ms": t_e, "decode_ms": t_d, "decode_with_index_ms": t_i,
+                    "encode_fps": nf / t_e * 1e3, "decode_fps": nf / t_d * 1e3, "decode_with_index_fps": nf / t_i * 1e3,
+                    "algorithmic_bytes": alg,
+                    "encode_frac_of_hbm_peak": alg / t_e / 1e6 / HBM_PEAK_GBPS,
+                    "decode_algorithmic_GBps": alg / t_d / 1e6,
+                    "decode_frac_of_hbm_peak": alg / t_d / 1e6 / HBM_PEAK_GBPS,
+                    "decode_with_index_frac_of_hbm_peak": alg / t_i / 1e6 / HBM_PEAK_GBPS,
+                    "decode_frac_of_measured_write": alg / t_d / 1e6 / measured["write_GBps"],
+                    "kernel_ms": km, "compression_ratio": nbytes / pb, "roundtrip_exact": True}
+
+        def run_leg(make, what):
             if args.headline_only:
-                raise RuntimeError("skipped (--headline-only)")
+                return {"error": "skipped (--headline-only)"}
+            try:
+                pxl = make()
+                r = leg(pxl, what)
+                del pxl
+                return r
+            except Exception as ex:      # informative legs only
+                return {"error": repr(ex)}
+
+        def make_noisy():
+            # Poisson(1.5) background clamped to 0..6 + 1/4096 peaks < 4000 (the generator of tools/dtype_time.py): the block width
+            # flips between 2 and 3 bits from block to block -- an explicit header every other block, the worst case for the
+            # header chain (Terse.hpp:360-372)
             g = torch.Generator(device=dev)
             g.manual_seed(1)
             bg = torch.poisson(torch.full((frames, N_VALUES), 1.5, device=dev), generator=g).clamp_(0, 6).to(torch.int32)
             hot = torch.rand((frames, N_VALUES), device=dev, generator=g) < (1.0 / 4096)
             pxn = torch.where(hot, torch.randint(0, 4000, (frames, N_VALUES), device=dev, generator=g, dtype=torch.int32), bg)
-            pxn = pxn.to(torch.int16).view(torch.uint16)
-            del bg, hot
-            en = codec.encode(pxn, out=out, workspace=ws, frame_offsets=offs, status=st_e)
-            torch.cuda.synchronize()
-            en.check()
-            nbytes = en.total_bytes()
-            t_e = timed(lambda: codec.encode(pxn, out=out, workspace=ws, frame_offsets=offs, status=st_e))
-            t_d = timed(lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d))
-            assert int(st_d[0].item()) == 0 and torch.equal(back.view(torch.int16), pxn.view(torch.int16))
-            want = O.encode(pxn[0].cpu().numpy())[0]
-            assert (out[: want.size].cpu().numpy() == want).all(), "noisy frame 0 differs from the CPU oracle"
-            noisy = {"workload": f"{frames} frames 512x512 uint16, Poisson(1.5) background 0..6 + 1/4096 peaks (block width changes every ~2 blocks)",
-                     "encode_ms": t_e, "decode_ms": t_d, "encode_fps": frames / t_e * 1e3, "decode_fps": frames / t_d * 1e3,
-                     "decode_algorithmic_GBps": (pix_bytes + nbytes) / t_d / 1e6,
-                     "decode_frac_of_hbm_peak": (pix_bytes + nbytes) / t_d / 1e6 / HBM_PEAK_GBPS,
-                     "compression_ratio": nbytes / pix_bytes, "roundtrip_exact": True}
-            del pxn
-        except Exception as ex:      # informative leg only
-            noisy = {"error": repr(ex)}
+            return pxn.to(torch.int16).view(torch.uint16)
+
+        from trpx_amd import workloads
+        noisy = run_leg(make_noisy, f"{frames} frames 512x512 uint16, Poisson(1.5) background 0..6 + 1/4096 peaks "
+                                    f"(block width changes every ~2 blocks)")
+        # BASELINE.md section 2's first anchor, the reference's own use case ("diffraction data", README.md:10): Poisson(3)
+        # background + 1/4096 12-bit peaks; the width changes on ~25 % of the blocks.  Counter-based (trpx_amd/workloads.py).
+        poisson3 = run_leg(lambda: workloads.poisson_u16(3.0, 0, frames, N_VALUES, device=dev),
+                           f"{frames} frames 512x512 uint16, counter-based Poisson(3) + 1/4096 12-bit peaks (width changes on ~25 % of the blocks)")
+        # a detector-shaped stack: 1030 x 1065 pixels (no multiple of 4 or of a cache line), 200 frames of 91 413 blocks each
+        mid_f = max(1, frames // 10)
+        midsize = run_leg(lambda: codec.synth(np.uint16, 0, mid_f, 1030 * 1065, device=dev),
+                          f"{mid_f} frames 1030x1065 uint16 synth-v1 (mid-size frames, odd pixel count)")
+        midsize_p3 = run_leg(lambda: workloads.poisson_u16(3.0, 0, mid_f, 1030 * 1065, device=dev),
+                             f"{mid_f} frames 1030x1065 uint16, counter-based Poisson(3) + 1/4096 12-bit peaks")
+        # frames whose byte size is no multiple of 128: every frame starts inside a cache line
+        oddsize = run_leg(lambda: codec.synth(np.uint16, 0, frames, 513 * 511, device=dev),
+                          f"{frames} frames 513x511 uint16 synth-v1 (frame size no multiple of a 128-byte line)")
 
         detail = {
             "encode_ms": enc_ms, "decode_ms": dec_ms,
@@ -443,7 +507,9 @@ def main():
             "encode_pixel_frac_of_hbm_peak": pix_bytes / enc_ms / 1e6 / HBM_PEAK_GBPS,
             "decode_pixel_frac_of_hbm_peak": pix_bytes / dec_ms / 1e6 / HBM_PEAK_GBPS,
             "decode_with_index_ms": dec_idx_ms, "decode_with_index_fps": frames / dec_idx_ms * 1e3,
-            "config3_4096x4096_int32": c4, "noisy_u16": noisy,
+            "decode_with_index_frac_of_hbm_peak": alg_bytes / dec_idx_ms / 1e6 / HBM_PEAK_GBPS,
+            "config3_4096x4096_int32": c4, "noisy_u16": noisy, "poisson3_u16": poisson3, "midsize_u16": midsize,
+            "midsize_poisson3_u16": midsize_p3, "oddsize_u16": oddsize, "peak_measured": measured,
             "kernel_ms": stage_ms, "compressed_bytes_per_gpu": total_bytes,
             "compression_ratio": total_bytes / pix_bytes, "oracle_check": oracle_check,
         }

@@ -218,11 +218,15 @@ public:
         if (groups && d_group_states.size() != groups * sizes.size() && !sizes.empty()) {
             std::vector<std::uint64_t> offs(sizes.size() + 1, 0);
             for (std::size_t f = 0; f < sizes.size(); ++f) offs[f + 1] = offs[f] + sizes[f];
-            d_group_states.assign(groups * sizes.size(), 0);
+            // computed into a local and then moved into the cache (write() is const like the reference's, Terse.hpp:454; the
+            // cache makes it -- like prolix(), Terse.hpp:387-388 -- unsafe to call on ONE object from two threads at once)
+            std::vector<std::uint64_t> states(groups * sizes.size(), 0);
             const unsigned max_bits = d_prolix_bits <= 8 ? 8 : d_prolix_bits <= 16 ? 16 : 32;
-            if (trpx_group_states_host(d_terse_data.data(), d_terse_data.size(), offs.data(), d_size, sizes.size(), d_block,
-                                       max_bits, d_group_states.data(), -1) != TRPX_OK)
-                d_group_states.clear();                                              // no group index: the file still gets its frame sizes
+            const int rc = trpx_group_states_host(d_terse_data.data(), d_terse_data.size(), offs.data(), d_size, sizes.size(), d_block,
+                                                  max_bits, states.data(), -1);
+            if (rc == TRPX_OK) d_group_states = std::move(states);
+            else if (rc == TRPX_ERR_UNSUPPORTED) d_group_states.clear();             // no group index for this stack: the file still gets its frame sizes
+            else detail::check(rc, "Terse::write (group states)");                   // device fault, no device, corrupt stack: not "no index"
         }
         const bool with_groups = groups && d_group_states.size() == groups * sizes.size();
         std::vector<char> buf(512 + (frame_index ? 21 * d_frame_sizes.size() + (with_groups ? 16 * d_group_states.size() : 0) : 0));

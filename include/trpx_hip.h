@@ -180,6 +180,13 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
                     void* pixels_dev, void* stream);
 
 /*
+ * Measured memory ceilings for the benchmark's roofline block (SURVEY.md section 8 row d): one grid-stride streaming
+ * kernel over `bytes` bytes, 16 bytes per lane, non-temporal.  mode 0 = read `src` (dst: a 4-byte device sink),
+ * 1 = write `dst`, 2 = copy src -> dst.  Device pointers, 16-byte aligned; stream-ordered.  Bench utility, not codec.
+ */
+int trpx_bench_stream(int mode, const void* src, void* dst, size_t bytes, void* stream);
+
+/*
  * Encoder selection: 0 = auto (default: the single-pass look-back encoder), 1 = always the two-pass pipeline.
  * Process-wide; also settable with the environment variable TRPX_ENCODE_PATH=twopass.
  */
@@ -187,12 +194,16 @@ int trpx_set_encode_path(int path);
 
 /*
  * Decoder selection (trpx_decode and the entry points built on it): 0 = auto (default: the per-frame decoder for
- * vector-aligned frames of < 2^26 bits, the position-parallel walk + tiled extraction for larger frames, the
- * basic kernels for unaligned frames, other block sizes and missing frame offsets), 1 = always the basic kernels, 2 = the
- * tiled route whenever its preconditions hold, 3 = the per-frame decoder whenever its preconditions hold (= auto for
- * trpx_decode; trpx_decode_indexed, which takes it from 1024 frames on, then uses it for any number).  Every route yields the same pixels (Terse.hpp:352-389); the setter exists for tests and A/B measurements.
+ * frames of < 2^26 bits -- block = 12, frame offsets given, any pixel count per frame, pointers aligned to the pixel
+ * type only --, the position-parallel walk + tiled extraction for larger frames, the basic kernels for other block
+ * sizes and missing frame offsets), 1 = always the basic kernels, 2 = the tiled route whenever its preconditions hold,
+ * 3 = the per-frame decoder whenever its preconditions hold (= auto for trpx_decode; trpx_decode_indexed, which takes
+ * it from 1024 frames on, then uses it for any number).  Every route yields the same pixels (Terse.hpp:352-389); the
+ * setter exists for tests and A/B measurements.
  * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames.
  * These two variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
+ * The tuned kernels issue 8- and 16-byte accesses at addresses that are only aligned to the pixel type (frames of any
+ * pixel count): they rely on the HSA unaligned-access mode, which ROCm enables on gfx950.
  */
 int trpx_set_decode_path(int path);
 
@@ -213,8 +224,8 @@ int trpx_encode_checked(int dtype, const void* pixels, size_t n_values, size_t n
  * Per-kernel timing for bench.py's roofline leg.  While enabled (per calling thread), trpx_encode /
  * trpx_decode record a hipEvent on `stream` before their first and after each of their kernels;
  * trpx_profile_read waits for the last launch and returns the elapsed ms of each stage
- * (single-pass encode: memset, encode_fused; two-pass encode: tile_bits, frame_scan, stack_scan,
- * zero_edges, pack; decode: walk, unpack).
+ * (single-pass encode: memset (k_zero_words), encode_fused, stitch; two-pass encode: tile_bits, frame_scan,
+ * stack_scan, zero_edges, pack; per-frame decode: decode_frames, deferred_frames; tiled decode: walk, unpack).
  * Returns the number of stages written.  Not graph-capturable while enabled.
  */
 int trpx_profile_enable(int on);

@@ -40,3 +40,46 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def _bench(extra_env, *flags):
+    env = dict(os.environ, **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_distributed_branch_runs_on_one_rank():
+    """The code an N > 1 run takes -- init_process_group("nccl"), the C-ABI size gather on its own RCCL communicator and side
+    stream, the barrier + MAX-over-ranks timing, the global-offset assertions behind the timed region -- rehearsed with one
+    rank in a fresh process (TRPX_BENCH_FORCE_DIST=1), next to the plain run of the same workload: the gather must be the
+    C-ABI one and may not cost the step more than 10 % (frames are independent, Terse.hpp:502-505: nothing but the sizes
+    is exchanged)."""
+    flags = ("--steps", "20", "--warmup", "3", "--headline-only", "--no-cpu-baseline")
+    plain = _bench({}, *flags)
+    forced = _bench({"TRPX_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"}, *flags)
+    assert plain["config"]["size_gather"] is None
+    assert "trpx_gather_frame_offsets" in forced["config"]["size_gather"], forced["config"]
+    assert forced["n_gpus"] == 1 and forced["scaling"] == "weak"
+    assert "byte-identical" in forced["oracle_check"]
+    assert forced["value"] > 0.9 * plain["value"], (forced["value"], plain["value"])
+
+
+@pytest.mark.gpu
+def test_bench_reports_the_workloads_the_headline_hides():
+    """poisson3 / mid-size / odd-size legs with their index-free and indexed decode times, and the box's measured ceilings."""
+    b = _bench({}, "--steps", "3", "--warmup", "1", "--frames", "200", "--no-cpu-baseline")
+    for k in ("noisy_u16", "poisson3_u16", "midsize_u16", "midsize_poisson3_u16", "oddsize_u16"):
+        leg = b[k]
+        assert leg.get("roundtrip_exact") is True, (k, leg)
+        for kk in ("encode_ms", "decode_ms", "decode_with_index_ms", "decode_frac_of_hbm_peak", "decode_with_index_frac_of_hbm_peak", "kernel_ms"):
+            assert kk in leg, (k, kk)
+        assert 0 < leg["decode_frac_of_hbm_peak"] < 1
+    pm = b["peak_measured"]
+    assert 2000 < pm["read_GBps"] < 8000 and 2000 < pm["write_GBps"] < 8000 and 2000 < pm["copy_GBps"] < 8000, pm
+    rf = b["roofline"]
+    assert rf["peak"] == 8000.0 and 0 < rf["frac"] < rf["frac_of_measured"] < 1.2 and rf["peak_measured"] > 0

@@ -366,7 +366,7 @@ def test_decode_index_side_channel(gpu, oracle):
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_many_small_frames_take_the_per_frame_decoder(gpu, oracle, dtype):
-    """>= 128 frames select k_decode_frames (walker wave + extraction waves per workgroup): differential test
+    """Stacks of small frames select k_decode_frames at any frame count (walker wave + extraction waves per workgroup): differential test
     against the oracle for every pixel type, mixed widths, partial last blocks, tiny and multi-super-step frames."""
     rng = np.random.RandomState(23)
     dt = np.dtype(dtype)
@@ -542,8 +542,7 @@ def test_two_pass_pipeline_and_basic_decoder_all_dtypes(gpu, oracle, dtype):
 def test_every_decode_path_every_dtype_block_to_block_width_changes(gpu, oracle, dtype):
     """One noisy stack per pixel type (the width changes with almost every block, including the type's full width),
     encoded by the single-pass encoder with the decode index, then decoded along every route the library has:
-    per-frame decoder (>= 128 frames), tiled decoder (< 128 frames), walk-free indexed decoder, serial walk without
-    offsets."""
+    per-frame decoder (auto), tiled decoder (forced), walk-free indexed decoder, serial walk without offsets."""
     import torch
     from trpx_amd import codec
     rng = np.random.RandomState(99)
@@ -961,7 +960,7 @@ def test_64bit_containers_with_wide_values(gpu, oracle, dtype, block):
 
 def test_large_frames_in_a_long_stack_take_the_tiled_path(gpu, oracle):
     """The per-frame decoder packs a block's bit position and width into 32 bits (frames of < 2^26 bits worst case).  A
-    stack of >= 128 frames whose worst case is larger (1500 x 1500 int32: 74 Mbit) must be routed to the tiled kernels --
+    stack whose frames' worst case is larger (1500 x 1500 int32: 74 Mbit) must be routed to the tiled kernels --
     also when the per-frame path is forced -- and decode exactly."""
     import torch
     from trpx_amd import codec

@@ -328,7 +328,7 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, boo
 
 hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st, const uint32_t* list = nullptr);
 
-// Fast path preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned.
+// Fast path preconditions (checked by the caller): block = 12, frame offsets known, frames of < 2^32 bits (T-aligned pointers, any pixel count).
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
     if (clear_status) {
         zero_status(a.status, st);

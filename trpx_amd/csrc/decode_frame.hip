@@ -694,8 +694,8 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// Preconditions (checked by the caller): frame offsets known, n_values % 4 == 0, pixels_out 16-byte aligned,
-// frames of < 2^26 bits (less one step's overshoot).
+// Preconditions (checked by the caller): block = 12, frame offsets known, frames of < 2^26 bits (less one step's overshoot);
+// pixels_out aligned to the pixel type, any pixel count per frame.
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st) {
     switch (dtype) {
     case 0: return launch_decode_frames_t<uint8_t>(a, st);

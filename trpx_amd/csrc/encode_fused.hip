@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     uint32_t w[kSub], up[kSub], len[kSub], inc[kSub];
     int nb[kSub];
     const bool has_full = g.n_values >= (uint64_t)kBlock;
-    const uint64_t max_first = has_full ? g.n_values - kBlock : 0;      // vector aligned: n_values % 4 == 0 on this path
+    const uint64_t max_first = has_full ? g.n_values - kBlock : 0;      // first value of the frame's last full block (any pixel count: loads are T-aligned)
     uint32_t h[Raw<T>::dw];              // block b0-1 (never the frame's last: full), for the tile's first header: wave 0 only
     if (has_full) {
 #pragma unroll

@@ -50,7 +50,7 @@ hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStre
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
 // converting decode (decode.hip): any integral output type with clamping, float, double; stream signedness given
 hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st);
-// tuned decode (decode_fast.hip): needs frame offsets, n_values % 4 == 0 and 16-byte aligned pixels_out
+// tuned decode (decode_fast.hip): needs block = 12, frame offsets, frames of < 2^32 bits; pixels_out aligned to the pixel type (any pixel count)
 hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, hipStream_t st, bool per_frame = false);   // per_frame (with an index): k_decode_frames_indexed
 // one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);

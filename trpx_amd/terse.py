@@ -241,8 +241,10 @@ class Terse:
                 del data
                 if rc == 0:
                     self._group_states = gs
+                elif rc == _lib.ERR_UNSUPPORTED:
+                    gs = None                                # no group index for this stack: the file still gets its frame sizes
                 else:
-                    gs = None                                # no group index: the file still gets its frame sizes
+                    check(rc)                                # device fault, no device, corrupt stack: not "no index"
         cap = 512 + (21 * len(self._frame_sizes) + (16 * gs.size if gs is not None else 0) if frame_index else 0)
         buf = C.create_string_buffer(cap)
         if frame_index and gs is not None:
