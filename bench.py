@@ -172,6 +172,11 @@ def main():
         if rank == 0:
             print(json.dumps({"selftest": True, "n_gpus": world, "master": os.environ["MASTER_ADDR"]}))
         sys.exit(0)
+    # stdout carries the ONE JSON line and nothing else: native libraries print banners to file descriptor 1 (RCCL: "RCCL
+    # version : ..." at communicator creation), so fd 1 points at stderr while the run lasts and the line goes to the saved one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # TRPX_BENCH_FORCE_DIST=1: run the RCCL code path (init, size gather, barrier) even with one rank (self test)
@@ -540,7 +545,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             result["cpu_baseline"] = cpu_baseline(px.cpu().numpy(), cores)
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if use_dist:
         gather.close()
         dist.barrier()

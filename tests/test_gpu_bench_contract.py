@@ -80,6 +80,6 @@ def test_bench_reports_the_workloads_the_headline_hides():
             assert kk in leg, (k, kk)
         assert 0 < leg["decode_frac_of_hbm_peak"] < 1
     pm = b["peak_measured"]
-    assert 2000 < pm["read_GBps"] < 8000 and 2000 < pm["write_GBps"] < 8000 and 2000 < pm["copy_GBps"] < 8000, pm
+    assert min(pm["read_GBps"], pm["write_GBps"], pm["copy_GBps"]) > 1000, pm      # (200 frames fit the Infinity Cache: no upper bound here)
     rf = b["roofline"]
-    assert rf["peak"] == 8000.0 and 0 < rf["frac"] < rf["frac_of_measured"] < 1.2 and rf["peak_measured"] > 0
+    assert rf["peak"] == 8000.0 and rf["peak_measured"] > 0 and abs(rf["frac_of_measured"] - rf["achieved"] / rf["peak_measured"]) < 1e-9
