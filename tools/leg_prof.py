@@ -32,7 +32,7 @@ def main():
     px, dt = make(leg, dev)
     nf, nv = px.shape[0], px[0].numel()
     ws_e, ws_d = codec.Workspace(dev), codec.Workspace(dev)
-    enc = codec.encode(px, workspace=ws_e, index=(mode == "idx"))
+    enc = codec.encode(px, workspace=ws_e, index=True if mode == "idx" else None)
     torch.cuda.synchronize(); enc.check()
     back = torch.empty_like(px)
     st = torch.empty(8, dtype=torch.int32, device=dev)

@@ -97,7 +97,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     __shared__ uint32_t s_pos[2][kPosEntries];
     uint32_t* const s_posx = &s_pos[0][0];
     constexpr uint32_t kPosBits = 26, kPosMask = (1u << kPosBits) - 1u;
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][Cfg::kOutStaged ? Cfg::kOutDw : 4];  // a group's pixels, per extraction wave
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[kFrameWaves - 1][Cfg::kOutStaged ? Cfg::kOutDw + kStageCarryDw : 4];  // a group's pixels as an image of its cache lines (store_group_lines), per extraction wave
     __shared__ uint32_t s_err;
 #ifdef TRPX_DEC_LDS_PAD
     __shared__ uint32_t s_pad[TRPX_DEC_LDS_PAD / 4];   // diagnostic build: fewer workgroups per CU
@@ -156,6 +156,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     const uint32_t n_steps = n_blocks <= sb0 ? 1u : 1u + (n_blocks - sb0 + kStepBlocks - 1) / kStepBlocks;
     auto step_begin = [&](uint32_t t) -> uint32_t { return t == 0u ? 0u : sb0 + (t - 1u) * kStepBlocks; };
     T* __restrict__ fout = pixels_out + frame * g.n_values;
+    // offset of the frame's first pixel inside its 128-byte line = that of every 64-block group (768 pixels: whole lines)
+    const uint32_t out_c = (uint32_t)((uintptr_t)fout & 127u);
 
 #ifdef TRPX_DEC_NO_STORE
     uint32_t diag_acc = 0;
@@ -446,6 +448,9 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #else
             const uint32_t gpw = (step_begin(s) - step0) / (uint32_t)((kFrameWaves - 1) * kWave);   // groups per wave in this super-step: 1 or kGpw
 #endif
+            // (blocks in front of n_whole are full blocks of this super-step: a group of 64 of them leaves as whole lines)
+            const uint32_t n_whole = nb_last == (uint32_t)kBlock || step1 < n_blocks ? step1 : step1 - 1u;
+            bool carry_live = false;                                                  // the row's front holds the group's first out_c bytes
 #pragma unroll 1
             for (uint32_t gq = 0; gq < gpw; ++gq) {
                 const uint32_t g0 = step0 + ((uint32_t)(wave - 1) * gpw + gq) * kWave;
@@ -494,8 +499,9 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                 if (Cfg::kOutStaged && todo == ~0ull) {
                     // 64 full blocks of 32-bit pixels: every lane leaves its 12 pixels in the wave's LDS row, then the wave
                     // stores the group 16 bytes per lane -- whole lines per store instruction instead of 48-byte runs
-                    uint32_t* const stage = s_out[wave - 1];
+                    uint32_t* const stage = s_out[wave - 1] + kStageCarryDw;            // (head room in front: store_group_lines)
                     uint32_t* const row = stage + lane * (kBlock * (uint32_t)sizeof(T) / 4u);
+                    const bool cont = gq + 1u < gpw && g0 + 2u * (uint32_t)kWave <= n_whole;   // this wave's next group is staged too
                     while (todo) {
                         const int l0 = __builtin_ctzll(todo);
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
@@ -517,7 +523,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    store_group<T>(stage, fout + (uint64_t)g0 * kBlock);
+                    store_group_lines<T>(stage, fout + (uint64_t)g0 * kBlock, out_c, carry_live, cont);
+                    carry_live = cont;
                     __builtin_amdgcn_wave_barrier();                                  // (the row is rewritten by the next group)
                 } else if constexpr (sizeof(T) == 4) {                                // 32-bit pixels, a group with fewer than 64 full blocks: stores inside the bodies
                     while (todo) {

@@ -6,6 +6,15 @@
 
 namespace trpx {
 
+// Vector types for accesses that are only aligned to the pixel type (frames of any pixel count start anywhere): the
+// compiler is told the real alignment and still emits one dwordx2 / dwordx4 (gfx950: unaligned-access-mode,
+// unaligned-ds-access).
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+typedef u4_t u4_a1 __attribute__((aligned(1)));
+typedef u2_t u2_a1 __attribute__((aligned(1)));
+typedef uint32_t u1_a1 __attribute__((aligned(1)));
+
 template <typename T> struct OutVec;
 template <> struct OutVec<uint8_t>  { typedef uint32_t type; };
 template <> struct OutVec<int8_t>   { typedef uint32_t type; };
@@ -19,7 +28,8 @@ template <typename T>
 __device__ __forceinline__ void store_block(T* __restrict__ dst, const uint32_t (&u)[kBlock]) {
     using V = typename OutVec<T>::type;
     constexpr int bits = PixelTraits<T>::bits;
-    V* q = reinterpret_cast<V*>(dst);
+    typedef V Vu __attribute__((aligned(1)));               // dst is aligned to T only
+    Vu* q = reinterpret_cast<Vu*>(dst);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         union { V vec; uint32_t x[sizeof(V) / 4]; } o;
@@ -38,15 +48,15 @@ __device__ __forceinline__ void store_block(T* __restrict__ dst, const uint32_t 
 template <typename T>
 __device__ __forceinline__ void stage_block(uint32_t* __restrict__ row, const uint32_t (&u)[kBlock]) {
     constexpr int bits = PixelTraits<T>::bits;
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef u2_t u2;
     if constexpr (bits == 32) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) reinterpret_cast<u2*>(row)[i] = u2{u[2 * i], u[2 * i + 1]};
+        for (int i = 0; i < 6; ++i) reinterpret_cast<u2*>(row)[i] = u2_t{u[2 * i], u[2 * i + 1]};
     } else if constexpr (bits == 16) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            reinterpret_cast<u2*>(row)[i] = u2{__builtin_amdgcn_perm(u[4 * i + 1], u[4 * i], 0x05040100u),
-                                               __builtin_amdgcn_perm(u[4 * i + 3], u[4 * i + 2], 0x05040100u)};
+            reinterpret_cast<u2*>(row)[i] = u2_t{__builtin_amdgcn_perm(u[4 * i + 1], u[4 * i], 0x05040100u),
+                                                 __builtin_amdgcn_perm(u[4 * i + 3], u[4 * i + 2], 0x05040100u)};
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -107,20 +117,20 @@ __device__ __forceinline__ void unpack_store_w(const uint32_t (&raw)[4 * RawQuad
             else f[k] = W >= 32 ? y : y & ((1u << (W & 31)) - 1u);
         }
     }
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef u4_a1 u4;                                                                // (dst is aligned to T only)
+    typedef u2_a1 u2;
     if constexpr (bits == 32) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            u4 o = {f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+            u4_t o = {f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
             __builtin_nontemporal_store(o, reinterpret_cast<u4*>(dst) + i);
         }
     } else if constexpr (bits == 16) {                                               // v_perm_b32: {hi.lo16, lo.lo16}
         uint32_t o[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) o[i] = __builtin_amdgcn_perm(f[2 * i + 1], f[2 * i], 0x05040100u);
-        u4 a = {o[0], o[1], o[2], o[3]};
-        u2 c = {o[4], o[5]};
+        u4_t a = {o[0], o[1], o[2], o[3]};
+        u2_t c = {o[4], o[5]};
         __builtin_nontemporal_store(a, reinterpret_cast<u4*>(dst));                  // 24 bytes: one 16-byte + one 8-byte store
         __builtin_nontemporal_store(c, reinterpret_cast<u2*>(dst) + 2);
     } else {
@@ -131,9 +141,9 @@ __device__ __forceinline__ void unpack_store_w(const uint32_t (&raw)[4 * RawQuad
             const uint32_t hi = __builtin_amdgcn_perm(f[4 * i + 3], f[4 * i + 2], 0x0c0c0400u);
             o[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
         }
-        u2 a = {o[0], o[1]};
-        __builtin_nontemporal_store(a, reinterpret_cast<u2*>(dst));   // 12 bytes (4-byte aligned: block = 12 bytes)
-        __builtin_nontemporal_store(o[2], reinterpret_cast<uint32_t*>(dst) + 2);
+        u2_t a = {o[0], o[1]};
+        __builtin_nontemporal_store(a, reinterpret_cast<u2*>(dst));   // 12 bytes
+        __builtin_nontemporal_store(o[2], reinterpret_cast<u1_a1*>(dst) + 2);
     }
 }
 
@@ -184,24 +194,24 @@ __device__ __forceinline__ void unpack_regs_w(const uint32_t (&raw)[4 * RawQuads
 // A block's packed pixels -> memory: 12 bytes as 8 + 4, 24 bytes as 16 + 8, 48 bytes as 3 x 16 (non-temporal).
 template <typename T>
 __device__ __forceinline__ void store_packed(T* __restrict__ dst, const uint32_t (&o)[PackedDwords<T>::n]) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef u4_a1 u4;                                                                // (dst is aligned to T only)
+    typedef u2_a1 u2;
     constexpr int bits = PixelTraits<T>::bits;
     if constexpr (bits == 32) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            u4 v = {o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+            u4_t v = {o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
             __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst) + i);
         }
     } else if constexpr (bits == 16) {
-        u4 a = {o[0], o[1], o[2], o[3]};
-        u2 c = {o[4], o[5]};
+        u4_t a = {o[0], o[1], o[2], o[3]};
+        u2_t c = {o[4], o[5]};
         __builtin_nontemporal_store(a, reinterpret_cast<u4*>(dst));
         __builtin_nontemporal_store(c, reinterpret_cast<u2*>(dst) + 2);
     } else {
-        u2 a = {o[0], o[1]};
-        __builtin_nontemporal_store(a, reinterpret_cast<u2*>(dst));                  // (4-byte aligned: block = 12 bytes)
-        __builtin_nontemporal_store(o[2], reinterpret_cast<uint32_t*>(dst) + 2);
+        u2_t a = {o[0], o[1]};
+        __builtin_nontemporal_store(a, reinterpret_cast<u2*>(dst));
+        __builtin_nontemporal_store(o[2], reinterpret_cast<u1_a1*>(dst) + 2);
     }
 }
 
@@ -306,25 +316,115 @@ __device__ __forceinline__ void unpack_stage_w(const uint32_t (&raw)[4 * RawQuad
     }
 }
 
-// The wavefront's staged group (64 blocks = 768 pixels, consecutive in `staging`) -> memory.  Every store instruction is
-// executed by all 64 lanes and writes whole 128-byte lines: 3072 bytes as three 16-byte-per-lane stores, 1536 bytes as one
-// 16-byte and one 8-byte-per-lane store, 768 bytes as one 8-byte and one 4-byte-per-lane store (no lane masks, no branches).
+// The wavefront's staged group (64 blocks = 768 pixels, consecutive in `staging`) -> memory, `group_dst` 128-byte aligned.
+// Every store instruction is executed by all 64 lanes and writes whole 128-byte lines: 3072 bytes as three 16-byte-per-lane
+// stores, 1536 bytes as one 16-byte and one 8-byte-per-lane store, 768 bytes as one 8-byte and one 4-byte-per-lane store (no
+// lane masks, no branches).  skip_line0: the lanes of the first instruction that cover the first line do not store.
 template <typename T>
-__device__ __forceinline__ void store_group(const uint32_t* __restrict__ staging, T* __restrict__ group_dst) {
+__device__ __forceinline__ void store_group(const uint32_t* __restrict__ staging, T* __restrict__ group_dst, bool skip_line0 = false) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const int lane = lane_id();
     uint32_t* dst = reinterpret_cast<uint32_t*>(group_dst);
     if constexpr (sizeof(T) == 4) {
+        if (!(skip_line0 && lane < 8))
+            __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 1; i < 3; ++i)
             __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[i * kWave + lane], reinterpret_cast<u4*>(dst) + i * kWave + lane);
     } else if constexpr (sizeof(T) == 2) {
-        __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
+        if (!(skip_line0 && lane < 8))
+            __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
         __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging + 256)[lane], reinterpret_cast<u2*>(dst + 256) + lane);
     } else {
-        __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging)[lane], reinterpret_cast<u2*>(dst) + lane);
+        if (!(skip_line0 && lane < 16))
+            __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging)[lane], reinterpret_cast<u2*>(dst) + lane);
         __builtin_nontemporal_store((staging + 128)[lane], dst + 128 + lane);
+    }
+}
+
+// The same for a frame that starts anywhere inside a cache line (most detectors: 1030 x 1065, 513 x 511 pixels ...).  A group
+// is 6 / 12 / 24 whole lines long, so every group of a frame starts at the same offset c = (address of the frame's first
+// pixel) & 127 inside its line.  The lanes stage their blocks exactly as for aligned frames (row byte = lane * block bytes:
+// aligned LDS writes); the row has kStageCarryDw dwords of head room IN FRONT of it, and the wave stores the 128-byte LINES
+// [group_dst - c, group_dst - c + G): each lane reads its 16 (8, 4) bytes c bytes in front of where an aligned frame would
+// read them -- dword-aligned LDS reads + one funnel shift per dword when c is no multiple of 4 -- so that every global store
+// instruction writes whole lines at aligned addresses.  The group's last c bytes are left over: a wave's next group, if it
+// follows at once (`cont`), finds them in the head room (`carry_live`); only the two ends of such a run are partial lines
+// (2 bytes per lane).  (Measured, 2000 x (513 x 511) u16: lane-owned rows stored from the frame's first pixel -- every 16-byte
+// store misaligned -- 0.32 ms; line images with the blocks staged at row byte c + ..., i.e. misaligned 8-byte LDS WRITES,
+// 0.36 ms; 512 x 512: 0.22 ms.)
+constexpr int kStageCarryDw = 32;
+template <int N>                                         // N dwords from LDS byte address `addr` (any 2-byte / 1-byte offset)
+__device__ __forceinline__ void lds_read_shifted(const uint32_t* __restrict__ lds0, uint32_t addr, uint32_t (&out)[N]) {
+    const uint32_t* p = lds0 + (addr >> 2);
+    const uint32_t sh = 8u * (addr & 3u);
+    uint32_t d[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) d[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+}
+// `row` = the group's row (the head room lies in front of it); all offsets below are row-relative bytes, biased by the head room
+template <typename T>
+__device__ __forceinline__ void store_group_lines(uint32_t* __restrict__ row, T* __restrict__ group_dst, uint32_t c,
+                                                  bool carry_live, bool cont) {
+    if (c == 0u) { store_group<T>(row, group_dst); return; }                  // (wave-uniform: line-aligned frames)
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    constexpr uint32_t G = kWave * kBlock * (uint32_t)sizeof(T);               // group bytes: a multiple of 128
+    constexpr uint32_t H = 4u * kStageCarryDw;                                 // head room, bytes
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t* const buf = row - kStageCarryDw;                                 // buffer byte H + i = row byte i = address group_dst + i
+    char* const bufb = reinterpret_cast<char*>(buf);
+    char* const base = reinterpret_cast<char*>(group_dst) - c;                 // 128-byte aligned
+    const uint32_t o0 = H - c;                                                 // buffer byte of the first line's first byte
+    const bool skip0 = !carry_live;                                            // the run's first line: only its bytes [c, 128) are ours
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            uint32_t x[4];
+            lds_read_shifted<4>(buf, o0 + 16u * (i * kWave + lane), x);
+            if (!(i == 0 && skip0 && lane < 8u))
+                __builtin_nontemporal_store(u4{x[0], x[1], x[2], x[3]}, reinterpret_cast<u4*>(base) + i * kWave + lane);
+        }
+    } else if constexpr (sizeof(T) == 2) {
+        uint32_t x[4], y[2];
+        lds_read_shifted<4>(buf, o0 + 16u * lane, x);
+        lds_read_shifted<2>(buf, o0 + 1024u + 8u * lane, y);
+        if (!(skip0 && lane < 8u)) __builtin_nontemporal_store(u4{x[0], x[1], x[2], x[3]}, reinterpret_cast<u4*>(base) + lane);
+        __builtin_nontemporal_store(u2{y[0], y[1]}, reinterpret_cast<u2*>(base + 1024) + lane);
+    } else {
+        uint32_t x[2], y[1];
+        lds_read_shifted<2>(buf, o0 + 8u * lane, x);
+        lds_read_shifted<1>(buf, o0 + 512u + 4u * lane, y);
+        if (!(skip0 && lane < 16u)) __builtin_nontemporal_store(u2{x[0], x[1]}, reinterpret_cast<u2*>(base) + lane);
+        __builtin_nontemporal_store(y[0], reinterpret_cast<uint32_t*>(base + 512) + lane);
+    }
+    if (skip0) {                                                             // the run's first line: its bytes [c, 128) = row bytes [0, 128 - c)
+        if constexpr (sizeof(T) == 1) {
+            if (2u * lane >= c) base[2u * lane] = bufb[o0 + 2u * lane];
+            if (2u * lane + 1u >= c) base[2u * lane + 1u] = bufb[o0 + 2u * lane + 1u];
+        } else {
+            if (2u * lane >= c) *reinterpret_cast<uint16_t*>(base + 2u * lane) = *reinterpret_cast<const uint16_t*>(bufb + o0 + 2u * lane);
+        }
+    }
+    // the group's last c bytes (row bytes [G - c, G)): into the head room for the next group, or out as the run's last line
+    if constexpr (sizeof(T) == 1) {
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const uint32_t i = lane + 64u * k;
+            if (i < c) {
+                const char v = bufb[H + G - c + i];
+                if (cont) bufb[o0 + i] = v; else (base + G)[i] = v;
+            }
+        }
+    } else {
+        if (2u * lane < c) {
+            const uint16_t v = *reinterpret_cast<const uint16_t*>(bufb + H + G - c + 2u * lane);
+            if (cont) *reinterpret_cast<uint16_t*>(bufb + o0 + 2u * lane) = v;
+            else *reinterpret_cast<uint16_t*>(base + G + 2u * lane) = v;
+        }
     }
 }
 

@@ -17,7 +17,10 @@ template <typename T> constexpr bool unpack_staged() { return sizeof(T) == 4; }
 #else
 template <typename T> constexpr bool unpack_staged() { return true; }
 #endif
-template <typename T> constexpr int unpack_stage_dwords() { return unpack_staged<T>() ? 4 * kWave * kBlock * (int)sizeof(T) / 4 : 4; }
+// (rows at a stride of one group behind one head room: store_group_lines reads up to 127 bytes in front of a row and uses only
+// what lies inside the row when no group continues another, as here -- the bytes in front may be the neighbour's)
+template <typename T> constexpr int unpack_stage_row_dwords() { return kWave * kBlock * (int)sizeof(T) / 4; }
+template <typename T> constexpr int unpack_stage_dwords() { return unpack_staged<T>() ? 4 * unpack_stage_row_dwords<T>() + kStageCarryDw : 4; }
 template <typename T>
 constexpr int unpack_image_dwords() { return unpack_sub_tiles<T>() * ((kThreads * max_block_bits<T>() + 31) / 32) + 12; }
 
@@ -117,12 +120,14 @@ __device__ __forceinline__ bool unpack_tile(const uint8_t* __restrict__ terse, u
         }
         if (unpack_staged<T>() && __ballot(nb[r] == kBlock) == ~0ull) {   // the wavefront's 64 blocks are all full: staged, coalesced stores
             if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
-            uint32_t* const st = s_stage + wave * (kWave * kBlock * (int)sizeof(T) / 4);
+            uint32_t* const st = s_stage + kStageCarryDw + wave * unpack_stage_row_dwords<T>();
+            T* const gdst = fout + (uint64_t)(b - (uint32_t)lane) * kBlock;
+            const uint32_t gc = (uint32_t)((uintptr_t)gdst & 127u);             // (a wavefront's groups are 256 blocks apart: each is its own run)
             stage_block<T>(st + lane * (kBlock * (int)sizeof(T) / 4), u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            store_group<T>(st, fout + (uint64_t)(b - (uint32_t)lane) * kBlock);
+            store_group_lines<T>(st, gdst, gc, false, false);
             __builtin_amdgcn_wave_barrier();                // (the row is rewritten in the next round)
         } else if (nb[r] == kBlock) {
             if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
