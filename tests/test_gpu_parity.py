@@ -959,9 +959,9 @@ def test_64bit_containers_with_wide_values(gpu, oracle, dtype, block):
 
 
 def test_large_frames_in_a_long_stack_take_the_tiled_path(gpu, oracle):
-    """The per-frame decoder packs a block's bit position and width into 32 bits (frames of < 2^26 bits worst case).  A
-    stack whose frames' worst case is larger (1500 x 1500 int32: 74 Mbit) must be routed to the tiled kernels --
-    also when the per-frame path is forced -- and decode exactly."""
+    """The per-frame decoder packs a block's bit position and width into 32 bits (units of < 2^26 bits worst case).  A
+    stack whose frames' worst case is larger (1500 x 1500 int32: 74 Mbit) is cut into parts (decode_part.hip) or routed to
+    the tiled kernels -- also when the per-frame path is forced -- and decodes exactly."""
     import torch
     from trpx_amd import codec
     frames, n = 130, 1500 * 1500
@@ -1230,3 +1230,93 @@ def test_frame_index_of_stacks_with_values_wider_than_32_bits(gpu, oracle, tmp_p
         clone.prolix(out, 2)
         assert (out == px[2]).all()
     del clone, r                                                              # two closes of one handle would crash here
+
+
+def _banded(px, rows, width, period, band, rng):
+    """Header-dense bands (Poisson(1.5) counts: the block width flips with every other block) in a run-dominated frame."""
+    a = px.reshape(rows, width).copy()
+    for r0 in range(period // 2, rows, period):
+        a[r0:r0 + band] = np.minimum(rng.poisson(1.5, a[r0:r0 + band].shape), 6).astype(px.dtype)
+    return a.reshape(-1)
+
+
+@pytest.mark.parametrize("dtype,rows,width,frames", [(np.uint16, 1030, 1065, 6), (np.int32, 1211, 997, 3), (np.uint8, 2048, 2048, 2),
+                                                       (np.int16, 613, 1999, 33)])
+def test_large_frames_are_cut_into_parts(gpu, oracle, dtype, rows, width, frames):
+    """Frames of more than 32 K blocks take the per-frame decoder part by part (decode_part.hip: start states inside runs of
+    equal widths, a counting walk per part, repairs of the links that did not close, the part table).  Run-dominated frames,
+    frames with header-dense bands (cuts without a run to start in, parts that are too dense: the frame falls back to the
+    position-parallel walk), a frame of noise; pixel counts that are no multiple of 12, frames that start anywhere in the
+    stack.  Every frame must decode exactly; the stream is the oracle's (Terse.hpp:352-389 against :500-549)."""
+    import torch
+    from trpx_amd import codec
+    rng = np.random.RandomState(rows)
+    n = rows * width
+    dt = np.dtype(dtype)
+    base = oracle.synth(np.uint16, 3, frames, n).astype(np.int64)
+    if dt.kind == "i":
+        base = base - 3
+    base = np.clip(base, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt)
+    for f in range(frames):
+        if f % 3 == 1:
+            base[f] = _banded(base[f], rows, width, 64, 6, rng)           # thin bands: the guess search reaches past them
+        elif f % 3 == 2:
+            base[f] = _banded(base[f], rows, width, 200, 60, rng)         # wide bands: plain guesses, dense parts
+    if frames > 4:
+        base[4] = np.minimum(rng.poisson(1.5, n), 6).astype(dt)           # all noise
+    px = torch.from_numpy(base).to(gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    o = enc.frame_offsets.cpu().numpy()
+    for f in (0, 1, frames - 1):
+        want, _ = oracle.encode(base[f])
+        assert enc.stack()[int(o[f]): int(o[f + 1])].cpu().numpy().tobytes() == want.tobytes()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0
+    assert torch.equal(back.view(torch.uint8), px.view(torch.uint8).reshape(frames, -1))
+    # a flipped bit in the middle of a large frame must not go unnoticed (every part checks the state it ends in)
+    bad = enc.stack().clone()
+    mid = int(o[1] + (o[2] - o[1]) // 2) if frames > 2 else int(o[0] + (o[1] - o[0]) // 2)
+    bad[mid] ^= 0x10
+    back2, st2 = codec.decode(bad, enc.frame_offsets, n, frames, dtype)
+    torch.cuda.synchronize()
+    got = back2.view(torch.uint8).reshape(frames, -1)
+    assert int(st2[0].item()) == 5 or not torch.equal(got, px.view(torch.uint8).reshape(frames, -1))
+
+
+def test_large_frames_every_part_link_repaired(gpu, oracle, tmp_path):
+    """The same route in a test build whose cuts never find a run to start in (make weakparts: -DTRPX_PART_FORCE_WEAK):
+    every part starts on a chain that is not the frame's, every link is open, and k_part_repair has to count every part
+    again from the true state up to the checkpoint where the chains have merged.  The frames change their width every 16
+    blocks (a chain that is not the frame's merges at an explicit header it meets on a block start; in a frame of long runs
+    it may not meet one before the part ends, and the frame then takes the other route -- which is why real cuts start
+    inside runs).  The build counts its verdicts in the status block: no frame may fall back, every link must have been
+    repaired, the pixels must be exact."""
+    variant = os.path.join(ROOT, "tools", "variants", "libtrpx_weakparts.so")
+    if not os.path.exists(variant):
+        pytest.skip("test variant not built (make -C trpx_amd/csrc weakparts)")
+    script = tmp_path / "t.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from trpx_amd import codec
+rng = np.random.RandomState(5)
+for dtype, n, frames in ((np.uint16, 1030 * 1065, 12), (np.int32, 2048 * 2048 + 5, 2)):
+    a = rng.randint(0, 8, (frames, n)).astype(dtype)
+    a[:, 0::192] = 9                                      # every 16th block is 4 bits wide
+    if np.dtype(dtype).kind == "i":
+        a[:, 1::384] = -9
+    px = torch.from_numpy(a).cuda()
+    enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
+    torch.cuda.synchronize()
+    s = st.cpu().numpy()
+    assert s[0] == 0 and torch.equal(back, px), s
+    assert s[2] == 0 and s[3] > 0 and s[5] == s[3] and s[6] == 0, s      # no fallback; plain guesses == repaired links; no failed repair
+print("OK")
+""")
+    r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -96,7 +96,7 @@ IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     l.total = l.defer + trpx::align_up(4 * (n_frames + 2), 256);
     return l;
 }
-struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, total; };
+struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, parts, part_ws, total; };
 DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     DecWs w;
     const size_t tiles = n_frames * (size_t)g.n_tiles;
@@ -105,7 +105,10 @@ DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     w.widths = trpx::align_up(w.tile_off + 8 * tiles, 16);
     w.seg = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
     w.defer = w.seg + trpx::seg_workspace_bytes(g, n_frames);
-    w.total = w.defer + trpx::align_up(4 * (n_frames + 2), 256);
+    w.parts = w.defer + trpx::align_up(4 * (n_frames + 2), 256);                // large frames on the per-frame route: the part table
+    const size_t P = trpx::parts_per_frame(g, n_frames);
+    w.part_ws = w.parts + (P > 1 ? trpx::align_up(sizeof(trpx::PartDesc) * n_frames * P, 256) : 0);
+    w.total = w.part_ws + trpx::part_workspace_bytes(g, n_frames);
     return w;
 }
 
@@ -292,7 +295,15 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     // (the per-frame decoder packs a block's bit position with its width into 32 bits: frames of < 2^26 bits less the
     // walker's ring offset and one step's overshoot)
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
-    if (fast_ok && frame26 && !force_tiles)
+    // larger frames, or frames of more than 32 K blocks: cut into parts of the size of a 512 x 512 frame first (decode_part.hip);
+    // a part's positions are relative to its own first bit, so the 2^26 limit applies to the part
+    a.parts_per_frame = trpx::parts_per_frame(g, n_frames);
+    const bool parts_ok = a.parts_per_frame > 1u && n_frames * (uint64_t)a.parts_per_frame < 0x7FFFFFFFull && a.defer;
+    if (parts_ok) {
+        a.parts = reinterpret_cast<trpx::PartDesc*>(ws + w.parts);
+        a.part_ws = ws + w.part_ws;
+    } else a.parts_per_frame = 1;
+    if (fast_ok && (parts_ok || (frame26 && trpx::parts_per_frame(g, n_frames) == 1u)) && !force_tiles)
         HIP_TRY(trpx::launch_decode_frames(out_dtype, a, static_cast<hipStream_t>(stream)));
     else if (fast_ok)
         HIP_TRY(trpx::launch_decode_fast(out_dtype, a, false, static_cast<hipStream_t>(stream)));

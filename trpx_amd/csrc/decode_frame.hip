@@ -77,12 +77,13 @@ __device__ __forceinline__ void lds_dma16(const uint32_t* src_uniform, uint32_t 
 // hands to the position-parallel walk, once that has written their index.  MODE 2: the walker walks, and the other waves write
 // the index (widths, group offsets) instead of pixels: trpx_build_index on stacks of small frames (header-dense frames are
 // handed to the position-parallel walk like in MODE 0).
-template <typename T, int MODE>
+template <typename T, int MODE, bool PARTS = false>
 __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                   const uint64_t* __restrict__ frame_offsets, const FrameGeom& g,
                                                   T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
-                                                  uint32_t* __restrict__ status, const uint64_t frame,
-                                                  const uint8_t* __restrict__ idx_widths, const uint64_t* __restrict__ idx_group_off) {
+                                                  uint32_t* __restrict__ status, const uint64_t item,
+                                                  const uint8_t* __restrict__ idx_widths, const uint64_t* __restrict__ idx_group_off,
+                                                  const PartDesc* __restrict__ parts = nullptr) {
     using Cfg = FrameCfg<T>;
     constexpr bool IDX = MODE == 1;
     constexpr int kStepBlocks = Cfg::kStepBlocks, kChunkDw = Cfg::kChunkDw;
@@ -110,10 +111,20 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 
     const uint32_t lane = (uint32_t)lane_id();
     const int hw_wave = wave_id();
+    // The unit of work: a whole frame (item = frame) or, with a part table, the blocks [b0, b1) of a frame with the chain state
+    // in front of them (encode_kernels.hpp: PartDesc).  Below, everything is relative to the unit: block numbers, bit positions
+    // (`limit` = the frame's bits behind the unit's first), the output pointer.
+    uint64_t frame = item;
+    uint32_t pb0 = 0, pb1 = g.n_blocks, ppos0 = 0, pw0 = 0, ppos1 = 0, pw1 = 0;
+    if constexpr (PARTS) {                                                // (without a part table all of this folds to constants)
+        const PartDesc d = parts[item];                                   // (uniform address: scalar loads)
+        frame = d.frame; pb0 = d.b0; pb1 = d.b1; ppos0 = d.pos0; pw0 = d.w0; ppos1 = d.pos1; pw1 = d.w1;
+        if (pb1 <= pb0) return;                                           // the frame took another route
+    }
     const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
     if (threadIdx.x == 0) {
-        s_err = (fe > fo && fe <= terse_bytes) ? 0u : 1u;
-        s_keep[0] = (uint64_t)(uintptr_t)status; s_keep[1] = (uint64_t)(uintptr_t)defer; s_keep[2] = frame;
+        s_err = (fe > fo && fe <= terse_bytes && (uint64_t)ppos0 < 8 * (fe - fo) && pb1 <= g.n_blocks) ? 0u : 1u;
+        s_keep[0] = (uint64_t)(uintptr_t)status; s_keep[1] = (uint64_t)(uintptr_t)defer; s_keep[2] = item;
     }
     // Which wave walks.  A workgroup's four waves land on the CU's four SIMDs, the first one on a SIMD that rotates from
     // workgroup to workgroup, and the k-th workgroup to arrive on a CU gets wave slot k on every SIMD (measured,
@@ -140,12 +151,13 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(terse);
     const uint64_t n_dw = (terse_bytes + 3) / 4;
     const bool base16 = ((uintptr_t)terse & 15) == 0;
-    const uint64_t frame_abit = 8 * fo;
-    const uint32_t limit = (uint32_t)(8 * (fe - fo));
+    const uint64_t frame_abit = 8 * fo + ppos0;
+    const uint32_t limit = (uint32_t)(8 * (fe - fo) - ppos0);
     const uint64_t frame_dw = frame_abit >> 5;
     const uint32_t frame_sh = (uint32_t)(frame_abit & 31);
-    const uint32_t n_blocks = g.n_blocks;
-    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(n_blocks - 1) * kBlock);
+    const uint32_t n_blocks = pb1 - pb0;
+    const bool at_end = pb1 == g.n_blocks;                                // the unit ends with the frame's last block
+    const uint32_t nb_last = at_end ? (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock) : (uint32_t)kBlock;
     // Super-steps: step 0 is short when frames can be handed over (one group per extraction wave: the decision "this
     // frame's headers are too dense for the serial walk" falls after 192 blocks instead of 768 -- a header-dense stack spends
     // 0.04 instead of 0.11 ms here before its frames go to the position-parallel walk); every later step is kStepBlocks.
@@ -155,7 +167,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     const uint32_t sb0 = defer ? (uint32_t)((kFrameWaves - 1) * kWave) : (uint32_t)kStepBlocks;   // (a multiple of 64 either way)
     const uint32_t n_steps = n_blocks <= sb0 ? 1u : 1u + (n_blocks - sb0 + kStepBlocks - 1) / kStepBlocks;
     auto step_begin = [&](uint32_t t) -> uint32_t { return t == 0u ? 0u : sb0 + (t - 1u) * kStepBlocks; };
-    T* __restrict__ fout = pixels_out + frame * g.n_values;
+    T* __restrict__ fout = pixels_out + frame * g.n_values + (uint64_t)pb0 * kBlock;
     // offset of the frame's first pixel inside its 128-byte line = that of every 64-block group (768 pixels: whole lines)
     const uint32_t out_c = (uint32_t)((uintptr_t)fout & 127u);
 
@@ -164,7 +176,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #endif
     // walker state (wave-uniform)
     int32_t c_lo = 0, c_hi = 0;                        // the window holds dwords [c_lo, c_hi) of the frame
-    uint32_t b = 0, w_prev = 0, pos = 0;               // next block, width of the block before it, bit position of its header in the frame
+    uint32_t b = 0, w_prev = pw0, pos = 0;             // next block, width of the block before it, bit position of its header (all relative to the unit)
 #ifndef TRPX_DEC_WALK_PRIO
 #define TRPX_DEC_WALK_PRIO 3
 #endif
@@ -180,7 +192,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                 const uint32_t beg_b = step_begin(s);
                 const uint32_t end_nom = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
                 uint32_t* const ent = s_posx + (s & 1u) * kPosEntries;
-                const uint8_t* __restrict__ wf = idx_widths + frame * n_blocks;
+                const uint8_t* __restrict__ wf = idx_widths + frame * g.n_blocks + pb0;
                 constexpr int kChunks = kStepBlocks / kWave;
                 uint32_t wq[kChunks];
 #pragma unroll
@@ -204,7 +216,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     bad = bad || wi > kMaxW;
                     if (bi < end_nom) {
                         ent[bi - beg_b] = (frame_sh + p) | (wp << kPosBits);
-                        if ((bi & (uint32_t)(kTileBlocks - 1)) == 0u && idx_group_off[frame * g.n_tiles + bi / (uint32_t)kTileBlocks] != (uint64_t)p) bad = true;
+                        if (((pb0 + bi) & (uint32_t)(kTileBlocks - 1)) == 0u && idx_group_off &&
+                            idx_group_off[frame * g.n_tiles + (pb0 + bi) / (uint32_t)kTileBlocks] != (uint64_t)ppos0 + p) bad = true;
                     }
                     pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     const uint32_t lastl = end_nom - b0 < (uint32_t)kWave ? end_nom - b0 - 1u : (uint32_t)kWave - 1u;
@@ -212,7 +225,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     if (pos > limit) bad = true;                                      // (positions stay below 2^26: the index is not trusted)
                 }
                 b = end_nom;
-                if (!__ballot(bad) && b == n_blocks) bad = !(pos <= limit && 1 + (uint64_t)pos / 8 == fe - fo);   // S_f = 1 + bits/8 (Terse.hpp:547)
+                if (!__ballot(bad) && b == n_blocks)                                  // S_f = 1 + bits/8 (Terse.hpp:547) / the next part's state
+                    bad = at_end ? !(pos <= limit && 1 + ((uint64_t)ppos0 + pos) / 8 == fe - fo) : !(ppos0 + pos == ppos1 && w_prev == pw1);
                 if (__ballot(bad) && lane == 0) s_err = 1u;
                 if (lane == 0) ent[b - beg_b] = (frame_sh + (pos <= limit ? pos : limit)) | (w_prev << kPosBits);
             } else if (s < n_steps) {
@@ -392,8 +406,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     if (pos > limit + 64u * 400u) { bad = true; break; }              // ran away: corrupt stream
                     if (b == n_blocks) break;
                 }
-                if (!bad && b == n_blocks)                                            // S_f = 1 + bits/8 (Terse.hpp:547)
-                    bad = !(pos <= limit && 1 + (uint64_t)pos / 8 == fe - fo);
+                if (!bad && b == n_blocks)                                            // S_f = 1 + bits/8 (Terse.hpp:547) / the next part's state
+                    bad = at_end ? !(pos <= limit && 1 + ((uint64_t)ppos0 + pos) / 8 == fe - fo) : !(ppos0 + pos == ppos1 && w_prev == pw1);
                 if (bad && lane == 0) s_err = 1u;
                 if (lane == 0) ent[b - beg_b] = (frame_sh + pos) | (w_prev << kPosBits);   // H(first block the walker has not seen)
                 // A stream with an explicit header every few blocks costs this walker a step per header (10 x the time of a
@@ -464,10 +478,10 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                 }
                 if constexpr (MODE == 2) {                                            // the index instead of the pixels
                     if (blk < step1) {
-                        const_cast<uint8_t*>(idx_widths)[frame * n_blocks + blk] = (uint8_t)w;
-                        if ((blk & (uint32_t)(kTileBlocks - 1)) == 0u)
-                            const_cast<uint64_t*>(idx_group_off)[frame * g.n_tiles + blk / (uint32_t)kTileBlocks] =
-                                (uint64_t)((ent[blk - step0] & kPosMask) - frame_sh);
+                        const_cast<uint8_t*>(idx_widths)[frame * g.n_blocks + pb0 + blk] = (uint8_t)w;
+                        if (((pb0 + blk) & (uint32_t)(kTileBlocks - 1)) == 0u)
+                            const_cast<uint64_t*>(idx_group_off)[frame * g.n_tiles + (pb0 + blk) / (uint32_t)kTileBlocks] =
+                                (uint64_t)ppos0 + ((ent[blk - step0] & kPosMask) - frame_sh);
                     }
                     continue;
                 }
@@ -619,6 +633,16 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
     decode_frame_body<T, 0>(terse, terse_bytes, frame_offsets, g, pixels_out, defer, status, blockIdx.x, nullptr, nullptr);
 }
 
+// The same over the PARTS of large frames (decode_part.hip has built the table): one workgroup per part.
+template <typename T>
+__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_parts(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               T* __restrict__ pixels_out, uint32_t* __restrict__ status,
+                                                               const PartDesc* __restrict__ parts) {
+    if (status[0] != 0u) return;
+    decode_frame_body<T, 0, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, blockIdx.x, nullptr, nullptr, parts);
+}
+
 // The same with the widths given (IDX above): every frame of the stack (list == nullptr) or the frames list[1 .. list[0]].
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_frames_indexed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
@@ -688,8 +712,18 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                       a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), defer, a.status);
+    if (a.parts && a.parts_per_frame > 1u) {
+        // Large frames: cut into parts first (decode_part.hip: a walk-only pass from guessed states inside runs of equal widths,
+        // verified link by link); frames whose parts cannot be established -- no runs to start from: header-dense data -- are
+        // listed in a.defer as whole frames and take the position-parallel walk + tiled extraction below.
+        if (!defer) return hipErrorInvalidValue;
+        const hipError_t e = launch_build_parts(a, (uint32_t)PixelTraits<T>::bits, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_decode_parts<T>), dim3(a.n_frames * a.parts_per_frame), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status, static_cast<const PartDesc*>(a.parts));
+    } else
+        hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), defer, a.status);
     prof.mark(st);
     if (defer) {
         const hipError_t e = launch_decode_deferred(PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)

@@ -1,0 +1,579 @@
+// PROLIX decode of LARGE frames on the per-frame route (gfx950 / CDNA4): cutting a frame into PARTS.
+//
+// The per-frame decoder (decode_frame.hip) puts one serial header walker (reference include/Terse.hpp:360-372: block b+1's
+// position is only known after block b's header) and three extraction waves on a frame.  For the 22 K blocks of a 512 x 512
+// frame that is the right grain; a 1030 x 1065 frame (91 K blocks) is a 4 x longer chain on 4 x fewer workgroups, a 2048 x
+// 2048 frame (350 K blocks) 16 x -- 200 frames of 1030 x 1065 decoded at 0.13 of the HBM peak, 128 frames of 2048 x 2048 at
+// 0.07 (on the tiled route).  A frame of more than kPartMaxBlocks blocks is therefore cut into P parts, every part a unit of
+// work of its own for the per-frame decoder (k_decode_parts), which needs the chain state in front of every part: the
+// bit position of its first block's header, the width of the block before it, and -- for the place of its pixels -- the
+// number of its first block.  This file finds them, with the serial walker's own cheap steps (one per RUN of equal widths):
+//
+//   k_part_guess    a start state S_p for every part p >= 1.  The parts are cut at bit positions X_p = p * L.  Behind X_p the
+//                   wavefront looks for a run of blocks that repeat their width: kPartEvid header bits 1 at stride 1 + 12 w
+//                   (bit-parallel: 2048 candidate positions per width and pass); a position kPartSkip blocks inside such a
+//                   run is a block start with all but certainty.  No run within 16 K bits: the plain (X_p, 0), which is
+//                   almost surely not a state of the chain -- but a chain started there merges with the true one at the first
+//                   explicit header it meets on a block start (its state after an explicit header does not depend on the
+//                   width before, Terse.hpp:362-370).
+//   k_part_walk     one wavefront per part p < P - 1 walks from S_p to the position of S_(p+1), counts the blocks and leaves
+//                   the state it arrives in (OUT_p) plus a checkpoint (state, blocks so far) every few thousand bits.
+//                   A part whose explicit headers are too dense for the serial walker (more than 1 in 6 blocks) stops:
+//                   its frame is the position-parallel walk's case.
+//   k_part_repair   one wavefront per link p -> p + 1 that is OPEN (OUT_p != S_(p+1)): the blocks of part p + 1 counted again
+//                   from OUT_p -- only until this chain meets the one k_part_walk walked there (a checkpoint), which in
+//                   run-dominated data is the next explicit header; the count follows from the checkpoint's.
+//   k_part_resolve  one wavefront per frame.  S_0 = (0, 0) is true (Terse.hpp:359, :505); a chain that starts in a true state
+//                   is true to its end; a link is closed, or repaired from the true OUT_p -- by induction every part's
+//                   start state, block count and end state are the true chain's, the prefix sums of the counts are the
+//                   parts' first blocks, and the part table is written.  A frame where this does not work out (a dense
+//                   part, a repair that ran into another repair, a part of more than kPartMaxBlocks blocks, a corrupt
+//                   stream) is listed as a whole for the route large frames took before (position-parallel walk + tiled
+//                   extraction, decode_seg.hip): guesses and repairs only ever steer the speed, never the result -- and
+//                   every part's decoder checks again that it ends in the next part's state, the last one that
+//                   S_f = 1 + bits/8 (Terse.hpp:547).
+//
+// HBM traffic: the stream once more (walk only: no pixels), 0.2 of the algorithmic bytes of a u16 stack.
+#include "codec_common.hpp"
+#include "encode_kernels.hpp"
+
+namespace trpx {
+
+constexpr int kPartChunkDw = 2048;             // the walker's stream window: 8 KB
+constexpr uint32_t kPartEvid = 24;             // header bits of evidence for a start inside a run
+constexpr uint32_t kPartSkip = 12;             // the start lies this many blocks inside the evidence (the bits in front of a run are 1 half the time)
+constexpr uint32_t kPartSearch = 8;            // passes of 2048 candidate positions behind X_p
+constexpr uint32_t kPartCk = 256;              // checkpoints per part
+constexpr uint32_t kPartWeak = 0x80000000u;    // PartState::w: a plain guess (not expected to be a state of the chain)
+
+struct PartState { uint32_t pos, w; };
+struct PartCk { uint32_t pos, w, cnt; };
+struct PartWalk {                              // what k_part_walk leaves per (frame, part p < P - 1)
+    uint32_t o_pos, o_w;                       // OUT_p: the state at the chain's first block start >= T_p
+    uint32_t cnt;                              // blocks started in [S_p, T_p)
+    uint32_t flags;                            // 1: the chain left the frame / held an illegal width; 2: too dense for the serial walker
+    uint32_t n_ck;                             // checkpoints left behind
+    uint32_t pad[3];
+};
+struct PartFix {                               // what k_part_repair leaves per (frame, part 1 <= p < P - 1)
+    uint32_t state;                            // 0: link closed, nothing done; 1: merged into the part's walk; 2: walked to T_p on its own; 3: failed
+    uint32_t cnt, o_pos, o_w;                  // the part's block count (and, state 2, its end state) from the true start
+};
+
+uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames) {
+    if (g.n_blocks <= kPartMaxBlocks || n_frames == 0) return 1u;
+    // enough parts to fill the GPU one and a half times over (8 workgroups per CU), of 4 K .. 16 K blocks
+    const uint64_t p_min = (g.n_blocks + kPartBlocks - 1u) / kPartBlocks, p_max = g.n_blocks / 4096u;
+    const uint64_t p_want = (3072u + n_frames - 1u) / n_frames;
+    const uint64_t hi = p_max > p_min ? p_max : p_min;
+    const uint64_t P = p_want < p_min ? p_min : (p_want > hi ? hi : p_want);
+    return (uint32_t)P;
+}
+struct PartWs { size_t states, walks, fixes, cks, total; };
+static PartWs part_ws_layout(size_t n_frames, size_t P) {
+    PartWs w;
+    w.states = 0;
+    w.walks = align_up(w.states + n_frames * P * sizeof(PartState), 256);
+    w.fixes = align_up(w.walks + n_frames * (P - 1) * sizeof(PartWalk), 256);
+    w.cks = align_up(w.fixes + n_frames * (P - 1) * sizeof(PartFix), 256);
+    w.total = align_up(w.cks + n_frames * (P - 1) * kPartCk * sizeof(PartCk), 256);
+    return w;
+}
+size_t part_workspace_bytes(const FrameGeom& g, size_t n_frames) {
+    const size_t P = parts_per_frame(g, n_frames);
+    return P > 1 ? part_ws_layout(n_frames, P).total : 0;
+}
+
+// One LDS-DMA piece (see decode_frame.hip): lane l's 16 bytes at `src` land at LDS byte address lds_base + 16 * l.
+__device__ __forceinline__ void part_lds_dma16(const uint32_t* src_uniform, uint32_t lane_byte_offset, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_offset), "s"(src_uniform), "s"(lds_base) : "memory");
+}
+
+struct PartWin {                               // the frame's stream behind an LDS window
+    const uint32_t* s32;
+    uint64_t n_dw, frame_dw;                   // dwords of the stream; dword of the frame's first bit
+    uint32_t frame_sh;                         // bit of the frame's first bit inside that dword
+    bool base16;
+    int32_t c_lo, c_hi;                        // the window holds dwords [c_lo, c_hi) of the frame
+};
+
+// Window := the kPartChunkDw dwords from the (16-byte aligned) dword that holds frame bit `pos` on.
+__device__ __forceinline__ void part_fill(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t pos) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t need_lo = (W.frame_sh + pos) >> 5;
+    W.c_lo = (int32_t)(((W.frame_dw + need_lo) & ~3ull) - W.frame_dw);
+    W.c_hi = W.c_lo + kPartChunkDw;
+    const uint64_t d0 = (uint64_t)((int64_t)W.frame_dw + W.c_lo);
+    __builtin_amdgcn_wave_barrier();           // (every lane is through with the old window)
+    if (W.base16 && (d0 & 3) == 0 && d0 + kPartChunkDw <= W.n_dw) {
+#pragma unroll
+        for (int it = 0; it < kPartChunkDw / (kWave * 4); ++it)
+            part_lds_dma16(W.s32 + d0 + it * kWave * 4, lane * 16u, (uint32_t)(uintptr_t)&s_chunk[it * kWave * 4]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        for (uint32_t i = lane * 4; i < (uint32_t)kPartChunkDw; i += kWave * 4) {
+            const uint64_t d = d0 + i;
+            uint4 x;
+            x.x = d < W.n_dw ? W.s32[d] : 0u; x.y = d + 1 < W.n_dw ? W.s32[d + 1] : 0u;
+            x.z = d + 2 < W.n_dw ? W.s32[d + 2] : 0u; x.w = d + 3 < W.n_dw ? W.s32[d + 3] : 0u;
+            *reinterpret_cast<uint4*>(&s_chunk[i]) = x;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 32 stream bits from frame bit q on (inside the window)
+__device__ __forceinline__ uint32_t part_bits(const PartWin& W, const uint32_t* __restrict__ s_chunk, uint32_t q) {
+    const uint32_t fbit = W.frame_sh + q - 32u * (uint32_t)W.c_lo;
+    const uint32_t i = fbit >> 5 < (uint32_t)kPartChunkDw ? fbit >> 5 : (uint32_t)kPartChunkDw - 1u;   // (s_chunk has 4 dwords of slack)
+    return __builtin_amdgcn_alignbit(s_chunk[i + 1u], s_chunk[i], fbit);
+}
+
+// A block start inside a run of equal widths at or behind frame bit X, or the plain guess.  kPartEvid header bits 1 at stride
+// s = 1 + 12 w from some q in [X + 2048 i, X + 2048 (i + 1)) on -- 32 candidate positions per lane and AND chain, the widths
+// in ascending order, i < kPartSearch -- make (q + kPartSkip * s, w) the state; inside a run of EMPTY blocks (every bit a
+// header bit 1) X itself is one.  (Payload bits pass the test with probability 2^-24 per candidate, and the first kPartSkip
+// of the evidence may be a neighbour's bits: a guess is only a guess, k_part_resolve verifies.)
+__device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t X, uint32_t limit, uint32_t max_w) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t s_max = 1u + (uint32_t)kBlock * max_w;
+    const PartState plain{X, kPartWeak};
+#ifdef TRPX_PART_FORCE_WEAK
+    return plain;                              // test build (make weakparts): every link is open and goes through k_part_repair
+#endif
+    for (uint32_t pass = 0; pass < kPartSearch; ++pass) {
+        const uint32_t X0 = X + 2048u * pass;
+        if ((uint64_t)X0 + 2048u + (uint64_t)kPartEvid * s_max + 128u > (uint64_t)limit) return plain;   // too close to the frame's end
+        part_fill(W, s_chunk, X0);
+        if (pass == 0u) {
+            const uint32_t a = lane < 4u ? part_bits(W, s_chunk, X0 + 32u * lane) : 0xFFFFFFFFu;
+            if (!__ballot(a != 0xFFFFFFFFu)) return PartState{X, 0u};
+        }
+        for (uint32_t w = 1; w <= max_w; ++w) {
+            const uint32_t s = 1u + (uint32_t)kBlock * w;
+            uint32_t a = 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < kPartEvid; k += 4u) {                   // (a wrong width's candidates are gone after a dozen bits)
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) a &= part_bits(W, s_chunk, X0 + 32u * lane + (k + i) * s);
+                if (!__ballot(a != 0u)) break;
+            }
+            const uint64_t hits = __ballot(a != 0u);
+            if (hits) {
+                const int l0 = __builtin_ctzll(hits);
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, l0);
+                return PartState{X0 + 32u * (uint32_t)l0 + (uint32_t)__builtin_ctz(a0) + kPartSkip * s, w};
+            }
+        }
+    }
+    return plain;
+}
+
+// Walks the chain from (pos, w) and counts the blocks that start in front of frame bit T; leaves the state at the first block
+// start >= T, and in ck[] the state and count at the first step end behind every `ck_every` bits (a state of the chain at a
+// block boundary: another chain that has merged with this one passes through it).  dense: more than one explicit header in 6
+// blocks over 2048 blocks and more -- the walk stops (two serial walks of such a part, this one and the decoder's,
+// cost more than the position-parallel walk of the frame).  tolerant: the walk started from a plain guess, i.e. on a chain
+// that is not the frame's until it has merged with it -- such a chain may hold anything, also widths the pixel type does not
+// have: it goes on from there with width 0 (what it counts in front of the merge is never used).  The steps are decode_frame.hip's (one per run of equal widths + the explicit header that ends it, the header
+// parsed on the scalar unit) without the position entries; the fast loop only takes steps whose 64 candidates all lie in
+// front of T and inside the window, the general step does the rest.
+__device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w_prev, uint32_t T,
+                                          uint32_t limit, uint32_t max_w, uint32_t& count, bool& bad, bool& dense,
+                                          PartCk* __restrict__ ck, uint32_t ck_every, uint32_t& n_ck, bool tolerant) {
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t b = 0, n_exp = 0, b_ref = 0, exp_ref = 0;
+    uint32_t ck_next = pos + ck_every;
+    n_ck = 0;
+    while (pos < T && !bad) {
+        if (pos >= ck_next) {
+            if (n_ck < kPartCk && lane == 0) ck[n_ck] = PartCk{pos, w_prev, b};
+            n_ck = n_ck < kPartCk ? n_ck + 1u : n_ck;
+            ck_next = pos + ck_every;
+            // (a chain that is not the frame's yet may look like anything, for as long as it takes to merge: a tolerant walk is
+            // never stopped -- a frame MOST of whose cuts are plain guesses does not get here, see k_part_walk)
+            if (!tolerant && b - b_ref >= 2048u && (n_exp - exp_ref) * 6u > b - b_ref) { dense = true; break; }
+        }
+        uint32_t stride = 1u + (uint32_t)kBlock * w_prev;
+        {   // the window holds the 64 candidates of a step from here
+            const uint32_t need_lo = (W.frame_sh + pos) >> 5;
+            const uint32_t need_hi = ((W.frame_sh + pos + 63u * stride) >> 5) + 2u;
+            if ((int32_t)need_lo < W.c_lo || (int32_t)need_hi > W.c_hi) part_fill(W, s_chunk, pos);
+        }
+        {
+            const uint32_t base8 = 8u * (uint32_t)(uintptr_t)&s_chunk[0];               // the window's LDS address, in bits
+            uint32_t pw = W.frame_sh + pos - 32u * (uint32_t)W.c_lo + base8;             // the header's bit address in LDS
+            uint32_t pw_end = 32u * (uint32_t)(W.c_hi - W.c_lo - 1) + base8;
+            const uint64_t t_rel = (uint64_t)W.frame_sh + T - 32ull * (uint64_t)(int64_t)W.c_lo;   // (c_lo >= -3; T >= pos: inside or behind the window)
+            if (t_rel + base8 < (uint64_t)pw_end) pw_end = (uint32_t)t_rel + base8;       // candidates stay in front of T
+            {   // ... and the fast steps end where the next checkpoint is due
+                const uint32_t c_pw = W.frame_sh + ck_next - 32u * (uint32_t)W.c_lo + base8 + 64u * stride;
+                if (ck_next - pos < 0x4000000u && c_pw < pw_end) pw_end = c_pw;
+            }
+            uint32_t pw_max = pw_end - 63u * stride;
+            uint32_t v_ls = __umul24(lane, stride);
+            uint32_t s_bad = 0, t_first, t_h, t_t, t_p, t_a, t_bits;
+            asm volatile(
+                "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"
+                "s_cbranch_scc0 9f\n"
+                "1:\n\t"
+                "v_add_u32 %[p], %[pw], %[ls]\n\t"                 // this lane's candidate header
+                "v_lshrrev_b32 %[a], 3, %[p]\n\t"
+                "v_and_b32 %[a], 0x1ffffffc, %[a]\n\t"
+                "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_alignbit_b32 %[bits], v63, v62, %[p]\n\t"
+                "v_and_b32 %[a], 1, %[bits]\n\t"
+                "v_cmp_eq_u32 vcc, 0, %[a]\n\t"                   // lanes whose block has an explicit header (Terse.hpp:361)
+                "s_cbranch_vccz 5f\n\t"
+                "s_ff1_i32_b64 %[first], vcc\n\t"
+                "v_readlane_b32 %[h], %[bits], %[first]\n\t"
+                "s_bfe_u32 %[w], %[h], 0x30001\n\t"               // Terse.hpp:362
+                "s_cmp_lg_u32 %[w], 7\n\t"
+                "s_cbranch_scc0 6f\n\t"
+                "s_addc_u32 %[b], %[b], %[first]\n\t"             // b += first + 1 (SCC = 1)
+                "s_add_i32 %[nexp], %[nexp], 1\n\t"
+                "s_mul_i32 %[t], %[first], %[stride]\n\t"
+                "s_mul_i32 %[stride], %[w], 12\n\t"
+                "s_add_i32 %[pw], %[pw], %[t]\n\t"
+                "s_add_i32 %[stride], %[stride], 1\n\t"
+                "s_add_i32 %[pw], %[pw], %[stride]\n\t"
+                "s_add_i32 %[pw], %[pw], 3\n"                      // pos += first * stride + 4 + 12 w
+                "3:\n\t"
+                "v_mul_u32_u24 %[ls], %[stride], %[lane]\n\t"
+                "s_mul_i32 %[t], %[stride], 63\n\t"
+                "s_sub_i32 %[pwmax], %[pwend], %[t]\n"
+                "4:\n\t"
+                "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_branch 9f\n"
+                "5:\n\t"                                           // 64 blocks repeat the width
+                "s_lshl_b32 %[t], %[stride], 6\n\t"
+                "s_add_i32 %[pw], %[pw], %[t]\n\t"
+                "s_add_i32 %[b], %[b], 64\n\t"
+                "s_branch 4b\n"
+                "6:\n\t"                                           // widths >= 7: Terse.hpp:364-370
+                "s_bfe_u32 %[t], %[h], 0x20004\n\t"
+                "s_add_i32 %[w], %[t], 7\n\t"
+                "s_mul_i32 %[t], %[first], %[stride]\n\t"
+                "s_add_i32 %[pw], %[pw], %[t]\n\t"
+                "s_add_i32 %[pw], %[pw], 6\n\t"
+                "s_cmp_lg_u32 %[w], 10\n\t"
+                "s_cbranch_scc1 7f\n\t"
+                "s_bfe_u32 %[t], %[h], 0x60006\n\t"
+                "s_add_i32 %[w], %[t], 10\n\t"
+                "s_add_i32 %[pw], %[pw], 6\n"
+                "7:\n\t"
+                "s_cmp_gt_u32 %[w], %[maxw]\n\t"
+                "s_cbranch_scc1 8f\n\t"
+                "s_add_i32 %[b], %[b], %[first]\n\t"
+                "s_add_i32 %[b], %[b], 1\n\t"
+                "s_add_i32 %[nexp], %[nexp], 1\n\t"
+                "s_mul_i32 %[stride], %[w], 12\n\t"
+                "s_add_i32 %[pw], %[pw], %[stride]\n\t"
+                "s_add_i32 %[stride], %[stride], 1\n\t"
+                "s_branch 3b\n"
+                "8:\n\t"
+                "s_mov_b32 %[bad], 1\n"
+                "9:\n"
+                : [pw] "+s"(pw), [b] "+s"(b), [nexp] "+s"(n_exp), [w] "+s"(w_prev), [stride] "+s"(stride), [pwmax] "+s"(pw_max),
+                  [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
+                  [a] "=&v"(t_a), [bits] "=&v"(t_bits)
+                : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w)
+                : "vcc", "scc", "memory", "v62", "v63");
+            pos = pw - base8 + 32u * (uint32_t)W.c_lo - W.frame_sh;
+            if (s_bad) {
+                if (!tolerant) { bad = true; break; }
+                w_prev = 0u;                                                              // (pos: behind the illegal header)
+            }
+        }
+        if (pos >= T) break;
+        if (pos > limit) { bad = true; break; }
+        stride = 1u + (uint32_t)kBlock * w_prev;
+        {
+            const uint32_t need_lo = (W.frame_sh + pos) >> 5;
+            const uint32_t need_hi = ((W.frame_sh + pos + 63u * stride) >> 5) + 2u;
+            if ((int32_t)need_lo < W.c_lo || (int32_t)need_hi > W.c_hi) { part_fill(W, s_chunk, pos); continue; }   // the window's end stopped the fast steps
+        }
+        // ---- general step: the candidates in front of T (Terse.hpp:360-372) ----
+        const uint32_t lpos = pos + lane * stride;
+        const uint32_t bits = part_bits(W, s_chunk, lpos);
+        const uint32_t k_raw = (T - pos + stride - 1u) / stride;              // candidates with lpos < T (>= 1)
+        const uint32_t kT = k_raw < 64u ? k_raw : 64u;
+        const uint64_t valid = kT >= 64u ? ~0ull : ((1ull << kT) - 1ull);
+        const uint64_t stop = ~(__ballot((bits & 1u) != 0u) & valid);
+        const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        if (first < kT) {                                                     // explicit header at candidate `first`
+            const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)first);
+            uint32_t w = (eb >> 1) & 7u, hl = 4;                              // Terse.hpp:362-370
+            if (w == 7u) {
+                w += (eb >> 4) & 3u; hl = 6;
+                if (w == 10u) { w += (eb >> 6) & 63u; hl = 12; }
+            }
+            if (w > max_w) {
+                if (!tolerant) { bad = true; break; }
+                w = 0u;
+            }
+            pos += first * stride + hl + (uint32_t)kBlock * w;
+            w_prev = w;
+            b += first + 1u;
+            ++n_exp;
+        } else {                                                              // they all repeat the width
+            pos += kT * stride;
+            b += kT;
+        }
+        if (pos > limit) { bad = true; break; }
+    }
+    count = b;
+}
+
+// Counts the blocks of a part again from the true state (pos, w) -- general steps only -- until the chain passes through a
+// checkpoint of the part's first walk (the chains have merged: the rest of that walk is this chain's) or reaches T.
+// Returns 1: merged, `count` = the part's blocks; 2: at T, `count` / (pos, w) are the part's count and end state; 3: failed.
+__device__ __forceinline__ uint32_t part_rewalk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w_prev, uint32_t T,
+                                                uint32_t limit, uint32_t max_w, const PartCk* __restrict__ ck, uint32_t n_ck,
+                                                uint32_t walk_cnt, uint32_t& count) {
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t b = 0, ci = 0;
+    PartCk c{0xFFFFFFFFu, 0u, 0u};
+    if (n_ck) c = ck[0];
+    while (pos < T) {
+        while (ci < n_ck && c.pos < pos) { ++ci; c = ci < n_ck ? ck[ci] : PartCk{0xFFFFFFFFu, 0u, 0u}; }
+        const uint32_t stride = 1u + (uint32_t)kBlock * w_prev;
+        {
+            const uint32_t need_lo = (W.frame_sh + pos) >> 5;
+            const uint32_t need_hi = ((W.frame_sh + pos + 63u * stride) >> 5) + 2u;
+            if ((int32_t)need_lo < W.c_lo || (int32_t)need_hi > W.c_hi) part_fill(W, s_chunk, pos);
+        }
+        const uint32_t lpos = pos + lane * stride;
+        const uint32_t bits = part_bits(W, s_chunk, lpos);
+        const uint32_t k_raw = (T - pos + stride - 1u) / stride;              // candidates with lpos < T (>= 1)
+        const uint32_t kT = k_raw < 64u ? k_raw : 64u;
+        const uint64_t valid = kT >= 64u ? ~0ull : ((1ull << kT) - 1ull);
+        const uint64_t stop = ~(__ballot((bits & 1u) != 0u) & valid);
+        const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        const uint32_t n_run = first < kT ? first : kT - 1u;                  // candidates 0 .. n_run are block starts in front of T, width before them: w_prev
+        // a checkpoint among them?
+        while (ci < n_ck && c.pos <= pos + n_run * stride) {
+            if ((c.pos - pos) % stride == 0u && c.w == w_prev) { count = b + (c.pos - pos) / stride + (walk_cnt - c.cnt); return 1u; }
+            ++ci; c = ci < n_ck ? ck[ci] : PartCk{0xFFFFFFFFu, 0u, 0u};
+        }
+        if (first < kT) {                                                     // explicit header at candidate `first` (Terse.hpp:362-370)
+            const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)first);
+            uint32_t w = (eb >> 1) & 7u, hl = 4;
+            if (w == 7u) {
+                w += (eb >> 4) & 3u; hl = 6;
+                if (w == 10u) { w += (eb >> 6) & 63u; hl = 12; }
+            }
+            if (w > max_w) return 3u;
+            pos += first * stride + hl + (uint32_t)kBlock * w;
+            w_prev = w;
+            b += first + 1u;
+        } else {
+            pos += kT * stride;
+            b += kT;
+        }
+        if (pos > limit) return 3u;
+    }
+    count = b;
+    return 2u;
+}
+
+// The frame's cut positions: X_p = p * L.
+__device__ __forceinline__ uint32_t part_len_bits(uint32_t limit, uint32_t P) {
+    return (uint32_t)((((uint64_t)limit + P - 1u) / P + 127u) & ~127ull);
+}
+
+struct PartFrame { PartWin W; uint32_t limit, L; bool ok; };
+__device__ __forceinline__ PartFrame part_frame(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                const uint64_t* __restrict__ frame_offsets, uint32_t frame, uint32_t P) {
+    PartFrame f{};
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    f.ok = fe > fo && fe <= terse_bytes && 8 * (fe - fo) < 0xF0000000ull;
+    if (!f.ok) return f;
+    f.W.s32 = reinterpret_cast<const uint32_t*>(terse);
+    f.W.n_dw = (terse_bytes + 3) / 4;
+    f.W.frame_dw = (8 * fo) >> 5;
+    f.W.frame_sh = (uint32_t)((8 * fo) & 31);
+    f.W.base16 = ((uintptr_t)terse & 15) == 0;
+    f.W.c_lo = f.W.c_hi = 0;
+    f.limit = (uint32_t)(8 * (fe - fo));
+    f.L = part_len_bits(f.limit, P);
+    return f;
+}
+
+__global__ __launch_bounds__(kWave) void k_part_guess(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                      const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                      PartState* __restrict__ states) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    const uint32_t frame = blockIdx.x / P, p = blockIdx.x % P;
+    const uint32_t lane = (uint32_t)lane_id();
+    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    PartState s{0u, 0u};                                                      // a frame starts at bit 0 with width 0 (Terse.hpp:359, :505)
+    if (p != 0u) {
+        PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
+        s = f.ok ? part_guess(f.W, s_chunk, p * f.L, f.limit, max_w) : PartState{0u, kPartWeak};
+    }
+    if (lane == 0) states[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kWave) void k_part_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                     const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                     const PartState* __restrict__ states, PartWalk* __restrict__ walks,
+                                                     PartCk* __restrict__ cks) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    const uint32_t frame = blockIdx.x / (P - 1u), p = blockIdx.x % (P - 1u);
+    const uint32_t lane = (uint32_t)lane_id();
+    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    PartWalk r{};
+    r.flags = 1u;
+    PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
+    const PartState s = states[(uint64_t)frame * P + p], t = states[(uint64_t)frame * P + p + 1u];
+    // a frame most of whose cuts found no run to start in is header-dense: not worth a walk (it takes the other route)
+    uint32_t n_weak = 0;
+    for (uint32_t q = lane; q < P; q += kWave) n_weak += (states[(uint64_t)frame * P + q].w & kPartWeak) != 0u ? 1u : 0u;
+    n_weak = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_weak), 63);
+#ifdef TRPX_PART_FORCE_WEAK
+    n_weak = 0;
+#endif
+    if (2u * n_weak > P) r.flags = 2u;
+    else if (f.ok && t.pos > s.pos && t.pos < f.limit) {
+        uint32_t pos = s.pos, w = s.w & ~kPartWeak, cnt = 0, n_ck = 0;
+        bool bad = false, dense = false;
+        const uint32_t span = t.pos - s.pos;
+        const uint32_t every = span / (kPartCk - 8u) > 4096u ? span / (kPartCk - 8u) : 4096u;
+        part_walk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cnt, bad, dense, cks + (uint64_t)blockIdx.x * kPartCk, every, n_ck,
+                  (s.w & kPartWeak) != 0u);
+        r.o_pos = pos; r.o_w = w; r.cnt = cnt; r.n_ck = n_ck; r.flags = (bad ? 1u : 0u) | (dense ? 2u : 0u);
+    }
+    if (lane == 0) walks[blockIdx.x] = r;
+}
+
+// One wavefront per part 1 <= p <= P - 2 (the frame's last part is not walked here: its start is simply OUT_(P-2)).
+__global__ __launch_bounds__(kWave) void k_part_repair(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                       const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                       const PartState* __restrict__ states, const PartWalk* __restrict__ walks,
+                                                       const PartCk* __restrict__ cks, PartFix* __restrict__ fixes) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    const uint32_t frame = blockIdx.x / (P - 1u), p = blockIdx.x % (P - 1u);
+    const uint32_t lane = (uint32_t)lane_id();
+    if (p == 0u) return;                                                      // (part 0 starts in the true state)
+    const uint64_t wi = (uint64_t)frame * (P - 1u) + p;
+    const PartWalk prev = walks[wi - 1u], mine = walks[wi];
+    const PartState s = states[(uint64_t)frame * P + p], t = states[(uint64_t)frame * P + p + 1u];
+    PartFix x{0u, 0u, 0u, 0u};
+    if (prev.flags == 0u && !(prev.o_pos == s.pos && prev.o_w == s.w)) {      // an open link behind a walk that arrived somewhere
+        x.state = 3u;
+        if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+        PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
+        if (f.ok && mine.flags == 0u && prev.o_pos < t.pos && t.pos < f.limit) {
+            uint32_t pos = prev.o_pos, w = prev.o_w, cnt = 0;
+            x.state = part_rewalk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cks + wi * kPartCk, mine.n_ck < kPartCk ? mine.n_ck : kPartCk,
+                                  mine.cnt, cnt);
+            x.cnt = cnt; x.o_pos = pos; x.o_w = w;
+        }
+    }
+    if (lane == 0) fixes[wi] = x;
+}
+
+// See the head of the file.  list[0] = count, list[1 + i] = frame | (dense: bit 31).
+__global__ __launch_bounds__(kWave) void k_part_resolve(const PartState* __restrict__ states, const PartWalk* __restrict__ walks,
+                                                        const PartFix* __restrict__ fixes, FrameGeom g, uint32_t P,
+                                                        PartDesc* __restrict__ parts, uint32_t* __restrict__ list,
+                                                        uint32_t* __restrict__ status) {
+    const uint32_t frame = blockIdx.x, lane = (uint32_t)lane_id();
+    const PartState* __restrict__ sf = states + (uint64_t)frame * P;
+    const PartWalk* __restrict__ wf = walks + (uint64_t)frame * (P - 1u);
+    const PartFix* __restrict__ xf = fixes + (uint64_t)frame * (P - 1u);
+    PartDesc* __restrict__ pf = parts + (uint64_t)frame * P;
+    bool ok = true, dense = false;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < P - 1u; base += kWave) {
+        const uint32_t p = base + lane;
+        const bool valid = p < P - 1u;
+        PartWalk r{};
+        PartFix x{};
+        PartState s{}, t{};
+        bool good = true;
+        uint32_t cnt = 0;
+        PartState st{0u, 0u}, en{0u, 0u};                                     // the part's true start and end states
+        if (valid) {
+            r = wf[p]; s = sf[p]; t = sf[p + 1u];
+            if (p > 0u) x = xf[p];
+            good = r.flags == 0u;
+            if (p == 0u || x.state == 0u) {                                   // starts in its guess: S_0, or the link in front of it is closed
+                st = PartState{s.pos, s.w & ~kPartWeak}; en = PartState{r.o_pos, r.o_w}; cnt = r.cnt;
+            } else {
+                const PartWalk q = wf[p - 1u];
+                st = PartState{q.o_pos, q.o_w};
+                cnt = x.cnt;
+                if (x.state == 1u) en = PartState{r.o_pos, r.o_w};
+                else if (x.state == 2u) { en = PartState{x.o_pos, x.o_w}; good = good && x.o_pos == r.o_pos && x.o_w == r.o_w; }   // (the next link was judged by r's end state)
+                else good = false;
+            }
+            good = good && cnt >= 1u && cnt <= kPartMaxBlocks;
+        }
+        ok = ok && !__ballot(valid && !good);
+        dense = dense || __ballot(valid && (r.flags & 2u) != 0u) != 0ull;
+#ifdef TRPX_PART_STATS
+        {   // diagnostic build: status[2..7] = fallback frames, plain guesses, bad / dense walks, repaired links, failed repairs, oversized parts
+            const uint32_t n3 = (uint32_t)__builtin_popcountll(__ballot(valid && p > 0u && (s.w & kPartWeak) != 0u));
+            const uint32_t n4 = (uint32_t)__builtin_popcountll(__ballot(valid && r.flags != 0u));
+            const uint32_t n5 = (uint32_t)__builtin_popcountll(__ballot(valid && p > 0u && (x.state == 1u || x.state == 2u)));
+            const uint32_t n6 = (uint32_t)__builtin_popcountll(__ballot(valid && p > 0u && x.state == 3u));
+            const uint32_t n7 = (uint32_t)__builtin_popcountll(__ballot(valid && r.flags == 0u && (cnt < 1u || cnt > kPartMaxBlocks)));
+            if (lane == 0) { atomicAdd(status + 3, n3); atomicAdd(status + 4, n4); atomicAdd(status + 5, n5); atomicAdd(status + 6, n6); atomicAdd(status + 7, n7); }
+        }
+#endif
+        const uint32_t c = valid && good ? cnt : 0u;
+        const uint32_t inc = wave_inclusive_scan(c);
+        if (valid && good) {
+            PartDesc d;
+            d.frame = frame; d.b0 = running + inc - c; d.b1 = d.b0 + c;
+            d.pos0 = st.pos; d.w0 = st.w; d.pos1 = en.pos; d.w1 = en.w; d.pad = 0u;
+            pf[p] = d;
+            if (p == P - 2u) {                                                // the frame's last part starts where this one ends
+                PartDesc e;
+                e.frame = frame; e.b0 = d.b1; e.b1 = g.n_blocks; e.pos0 = en.pos; e.w0 = en.w; e.pos1 = 0u; e.w1 = 0u; e.pad = 0u;
+                pf[P - 1u] = e;
+            }
+        }
+        running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (running >= g.n_blocks) ok = false;                                // (the last part holds at least the frame's last block)
+    }
+    if (ok && g.n_blocks - running > kPartMaxBlocks) ok = false;
+    if (!ok) {                                                                // the whole frame takes the other route
+        __builtin_amdgcn_s_waitcnt(0);
+        for (uint32_t p = lane; p < P; p += kWave) { PartDesc d{}; d.frame = frame; pf[p] = d; }
+        if (lane == 0) list[1u + atomicAdd(&list[0], 1u)] = frame | (dense ? 0x80000000u : 0u);
+#ifdef TRPX_PART_STATS
+        if (lane == 0) atomicAdd(status + 2, 1u);
+#endif
+    }
+}
+
+hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
+    const uint32_t P = a.parts_per_frame;
+    if (P < 2u || !a.parts || !a.part_ws || !a.defer) return hipErrorInvalidValue;
+    const PartWs l = part_ws_layout(a.n_frames, P);
+    char* ws = static_cast<char*>(a.part_ws);
+    PartState* states = reinterpret_cast<PartState*>(ws + l.states);
+    PartWalk* walks = reinterpret_cast<PartWalk*>(ws + l.walks);
+    PartFix* fixes = reinterpret_cast<PartFix*>(ws + l.fixes);
+    PartCk* cks = reinterpret_cast<PartCk*>(ws + l.cks);
+    const dim3 links(a.n_frames * (P - 1u));
+    hipLaunchKernelGGL(k_part_guess, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
+                       states);
+    hipLaunchKernelGGL(k_part_walk, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
+                       static_cast<const PartState*>(states), walks, cks);
+    hipLaunchKernelGGL(k_part_repair, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
+                       static_cast<const PartState*>(states), static_cast<const PartWalk*>(walks), static_cast<const PartCk*>(cks), fixes);
+    hipLaunchKernelGGL(k_part_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartState*>(states),
+                       static_cast<const PartWalk*>(walks), static_cast<const PartFix*>(fixes), a.geom, P, a.parts, a.defer, a.status);
+    return hipGetLastError();
+}
+
+}  // namespace trpx

@@ -24,6 +24,18 @@ struct EncodeArgs {
     uint64_t*   idx_group_off; // n_frames * n_tiles (frame-relative bit offset of every 256-block group)
 };
 
+// A PART of a frame: the blocks [b0, b1) with the chain state in front of b0 (decode_part.hip).  Frames of more than
+// kPartMaxBlocks blocks are cut into parts of about kPartBlocks blocks so that the per-frame decoder -- one serial walker per
+// workgroup -- works on pieces of the size of a 512 x 512 frame whatever the frame size: `pos0` / `w0` = bit position of block
+// b0's header inside the frame and width of the block before it, `pos1` / `w1` = the same for block b1 (checked by the part's
+// walker when it gets there; the frame's last part checks S_f = 1 + bits/8 instead, Terse.hpp:547).  b1 <= b0: nothing to do
+// (the frame took another route).
+struct PartDesc {
+    uint32_t frame, b0, b1, pos0, w0, pos1, w1, pad;
+};
+constexpr uint32_t kPartBlocks = 16384;            // blocks per part, at most about (parts are cut at bit positions; stacks of few frames get smaller parts)
+constexpr uint32_t kPartMaxBlocks = 32768;         // frames of up to this many blocks are one part; no part may hold more
+
 struct DecodeArgs {
     const uint8_t*  terse;         // device
     size_t          terse_bytes;
@@ -39,7 +51,15 @@ struct DecodeArgs {
     uint32_t*       defer;         // 2 + n_frames words, 8-byte aligned (may be null): [0] = count, [1 + i] = frames the per-frame decoder hands to the position-parallel path
     void*           seg_ws;        // seg_workspace_bytes(): segment states of the position-parallel walk (decode_seg.hip)
     bool            index_per_frame = false;   // launch_walk_only: many small frames, use the per-frame walker (launch_index_frames)
+    // frames of more than kPartMaxBlocks blocks on the per-frame route: the part table and the scratch of its construction
+    PartDesc*       parts = nullptr;           // n_frames * parts_per_frame entries
+    uint32_t        parts_per_frame = 1;
+    void*           part_ws = nullptr;         // part_workspace_bytes()
 };
+uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames);
+size_t part_workspace_bytes(const FrameGeom& g, size_t n_frames);
+// decode_part.hip: fills a.parts for every frame; frames whose parts cannot be established are listed in a.defer (whole frames)
+hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
 // any block size (encode.hip, correct-first kernels): geom.block != 12
