@@ -77,7 +77,10 @@ __device__ __forceinline__ void lds_dma16(const uint32_t* src_uniform, uint32_t 
 // hands to the position-parallel walk, once that has written their index.  MODE 2: the walker walks, and the other waves write
 // the index (widths, group offsets) instead of pixels: trpx_build_index on stacks of small frames (header-dense frames are
 // handed to the position-parallel walk like in MODE 0).
-template <typename T, int MODE, bool PARTS = false>
+// LINES: the frames / parts may start anywhere inside a 128-byte line of the output and the extraction waves write line images
+// (store_group_lines); without it the groups are stored from their first pixel (line-aligned frames -- the host checks --, and
+// the kernels without a walker, which are faster that way even when the frames are not aligned).
+template <typename T, int MODE, bool PARTS = false, bool LINES = false>
 __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                   const uint64_t* __restrict__ frame_offsets, const FrameGeom& g,
                                                   T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
@@ -169,7 +172,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     auto step_begin = [&](uint32_t t) -> uint32_t { return t == 0u ? 0u : sb0 + (t - 1u) * kStepBlocks; };
     T* __restrict__ fout = pixels_out + frame * g.n_values + (uint64_t)pb0 * kBlock;
     // offset of the frame's first pixel inside its 128-byte line = that of every 64-block group (768 pixels: whole lines)
-    const uint32_t out_c = (uint32_t)((uintptr_t)fout & 127u);
+    const uint32_t out_c = LINES ? (uint32_t)((uintptr_t)fout & 127u) : 0u;
 
 #ifdef TRPX_DEC_NO_STORE
     uint32_t diag_acc = 0;
@@ -181,6 +184,39 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #define TRPX_DEC_WALK_PRIO 3
 #endif
     if (wave == 0) __builtin_amdgcn_s_setprio(TRPX_DEC_WALK_PRIO);      // the walk is the critical path
+    // MODE 1: the widths of the super-step after the one being filled wait in LDS (s_wnext[chunk * 64 + lane]); the filler
+    // requests them before it computes and parks them behind -- in registers across the loop they would be live in the
+    // extraction waves' code too (spills at 64 VGPRs)
+    // (requested four widths per lane and load -- one unaligned dword: three registers in flight per 768 blocks, not twelve)
+    constexpr int kIdxChunks = IDX ? kStepBlocks / kWave : 1;
+    constexpr int kIdxQuads = IDX ? kStepBlocks / (4 * kWave) : 1;
+    __shared__ __attribute__((aligned(4))) uint8_t s_wnext[IDX ? kStepBlocks : 4];
+    [[maybe_unused]] auto idx_load = [&](uint32_t ss, uint32_t (&dst)[kIdxQuads]) {
+        const uint8_t* __restrict__ wfl = idx_widths + frame * g.n_blocks + pb0;
+        const uint32_t bb = step_begin(ss), be = step_begin(ss + 1u) < n_blocks ? step_begin(ss + 1u) : n_blocks;
+#pragma unroll
+        for (int j = 0; j < kIdxQuads; ++j) {                                         // (all loads in flight before the first is used)
+            const uint32_t bi = bb + 4u * ((uint32_t)j * kWave + lane);
+            uint32_t v = 0u;
+            if (bi + 4u <= be) __builtin_memcpy(&v, wfl + bi, 4);
+            else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) v |= bi + k < be ? (uint32_t)wfl[bi + k] << (8u * k) : 0u;
+            }
+            dst[j] = v;
+        }
+    };
+    [[maybe_unused]] auto idx_park = [&](const uint32_t (&src)[kIdxQuads]) {
+#pragma unroll
+        for (int j = 0; j < kIdxQuads; ++j) reinterpret_cast<uint32_t*>(s_wnext)[j * kWave + lane] = src[j];
+    };
+    if constexpr (IDX) {
+        if (wave == 0) {
+            uint32_t w0[kIdxQuads];
+            idx_load(0u, w0);
+            idx_park(w0);
+        }
+    }
 
 #ifdef TRPX_DEC_STAMPS
     uint64_t st_work = 0, st_wait = 0, st_t0 = __builtin_readcyclecounter(), st_start = st_t0;
@@ -192,17 +228,15 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                 const uint32_t beg_b = step_begin(s);
                 const uint32_t end_nom = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
                 uint32_t* const ent = s_posx + (s & 1u) * kPosEntries;
-                const uint8_t* __restrict__ wf = idx_widths + frame * g.n_blocks + pb0;
-                constexpr int kChunks = kStepBlocks / kWave;
-                uint32_t wq[kChunks];
+                // this super-step's widths were requested a super-step ago (idx_next: the filler's loop would otherwise wait for a
+                // global load's round trip per super-step -- 29 per 512 x 512 frame, where the walker refills its window 13 times)
+                uint32_t wq[kIdxChunks], wn[kIdxQuads];
 #pragma unroll
-                for (int i = 0; i < kChunks; ++i) {                                    // (all loads in flight before the first is used)
-                    const uint32_t bi = beg_b + (uint32_t)i * kWave + lane;
-                    wq[i] = bi < end_nom ? (uint32_t)wf[bi] : 0u;
-                }
+                for (int i = 0; i < kIdxChunks; ++i) wq[i] = s_wnext[i * kWave + lane];
+                if (s + 1u < n_steps) idx_load(s + 1u, wn);
                 bool bad = false;
 #pragma unroll
-                for (int i = 0; i < kChunks; ++i) {
+                for (int i = 0; i < kIdxChunks; ++i) {
                     const uint32_t b0 = beg_b + (uint32_t)i * kWave;
                     if (b0 >= end_nom) continue;                                      // (wave-uniform; no break: the loop has to unroll, wq[] lives in registers)
                     const uint32_t bi = b0 + lane, wi = wq[i];
@@ -229,6 +263,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     bad = at_end ? !(pos <= limit && 1 + ((uint64_t)ppos0 + pos) / 8 == fe - fo) : !(ppos0 + pos == ppos1 && w_prev == pw1);
                 if (__ballot(bad) && lane == 0) s_err = 1u;
                 if (lane == 0) ent[b - beg_b] = (frame_sh + (pos <= limit ? pos : limit)) | (w_prev << kPosBits);
+                if (s + 1u < n_steps) idx_park(wn);
             } else if (s < n_steps) {
                 const uint32_t buf = s & 1u;
                 const uint32_t beg_b = step_begin(s);
@@ -463,8 +498,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
             const uint32_t gpw = (step_begin(s) - step0) / (uint32_t)((kFrameWaves - 1) * kWave);   // groups per wave in this super-step: 1 or kGpw
 #endif
             // (blocks in front of n_whole are full blocks of this super-step: a group of 64 of them leaves as whole lines)
-            const uint32_t n_whole = nb_last == (uint32_t)kBlock || step1 < n_blocks ? step1 : step1 - 1u;
-            bool carry_live = false;                                                  // the row's front holds the group's first out_c bytes
+            [[maybe_unused]] const uint32_t n_whole = nb_last == (uint32_t)kBlock || step1 < n_blocks ? step1 : step1 - 1u;
+            [[maybe_unused]] bool carry_live = false;                                 // the row's front holds the group's first out_c bytes
 #pragma unroll 1
             for (uint32_t gq = 0; gq < gpw; ++gq) {
                 const uint32_t g0 = step0 + ((uint32_t)(wave - 1) * gpw + gq) * kWave;
@@ -515,7 +550,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     // stores the group 16 bytes per lane -- whole lines per store instruction instead of 48-byte runs
                     uint32_t* const stage = s_out[wave - 1] + kStageCarryDw;            // (head room in front: store_group_lines)
                     uint32_t* const row = stage + lane * (kBlock * (uint32_t)sizeof(T) / 4u);
-                    const bool cont = gq + 1u < gpw && g0 + 2u * (uint32_t)kWave <= n_whole;   // this wave's next group is staged too
+                    [[maybe_unused]] const bool cont = LINES && gq + 1u < gpw && g0 + 2u * (uint32_t)kWave <= n_whole;   // this wave's next group is staged too
                     while (todo) {
                         const int l0 = __builtin_ctzll(todo);
                         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l0);
@@ -537,8 +572,11 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    store_group_lines<T>(stage, fout + (uint64_t)g0 * kBlock, out_c, carry_live, cont);
-                    carry_live = cont;
+                    if constexpr (!LINES) store_group<T, false>(stage, fout + (uint64_t)g0 * kBlock);
+                    else {
+                        store_group_lines<T>(stage, fout + (uint64_t)g0 * kBlock, out_c, carry_live, cont);
+                        carry_live = cont;
+                    }
                     __builtin_amdgcn_wave_barrier();                                  // (the row is rewritten by the next group)
                 } else if constexpr (sizeof(T) == 4) {                                // 32-bit pixels, a group with fewer than 64 full blocks: stores inside the bodies
                     while (todo) {
@@ -625,12 +663,12 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     }
 }
 
-template <typename T>
+template <typename T, bool LINES>
 __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ defer,
                                                                uint32_t* __restrict__ status) {
-    decode_frame_body<T, 0>(terse, terse_bytes, frame_offsets, g, pixels_out, defer, status, blockIdx.x, nullptr, nullptr);
+    decode_frame_body<T, 0, false, LINES>(terse, terse_bytes, frame_offsets, g, pixels_out, defer, status, blockIdx.x, nullptr, nullptr);
 }
 
 // The same over the PARTS of large frames (decode_part.hip has built the table): one workgroup per part.
@@ -640,7 +678,7 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ status,
                                                                const PartDesc* __restrict__ parts) {
     if (status[0] != 0u) return;
-    decode_frame_body<T, 0, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, blockIdx.x, nullptr, nullptr, parts);
+    decode_frame_body<T, 0, true, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, blockIdx.x, nullptr, nullptr, parts);
 }
 
 // The same with the widths given (IDX above): every frame of the stack (list == nullptr) or the frames list[1 .. list[0]].
@@ -721,8 +759,11 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_decode_parts<T>), dim3(a.n_frames * a.parts_per_frame), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                            a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status, static_cast<const PartDesc*>(a.parts));
-    } else
-        hipLaunchKernelGGL((k_decode_frames<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+    } else if ((a.geom.n_values * sizeof(T)) % 128u == 0u && (uintptr_t)a.pixels_out % 128u == 0u)   // every frame starts a cache line
+        hipLaunchKernelGGL((k_decode_frames<T, false>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                           a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), defer, a.status);
+    else
+        hipLaunchKernelGGL((k_decode_frames<T, true>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                            a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), defer, a.status);
     prof.mark(st);
     if (defer) {

@@ -42,7 +42,10 @@ namespace trpx {
 constexpr int kPartChunkDw = 2048;             // the walker's stream window: 8 KB
 constexpr uint32_t kPartEvid = 24;             // header bits of evidence for a start inside a run
 constexpr uint32_t kPartSkip = 12;             // the start lies this many blocks inside the evidence (the bits in front of a run are 1 half the time)
-constexpr uint32_t kPartSearch = 8;            // passes of 2048 candidate positions behind X_p
+#ifndef TRPX_PART_SEARCH
+#define TRPX_PART_SEARCH 8
+#endif
+constexpr uint32_t kPartSearch = TRPX_PART_SEARCH;   // passes of 2048 candidate positions behind X_p
 constexpr uint32_t kPartCk = 256;              // checkpoints per part
 constexpr uint32_t kPartWeak = 0x80000000u;    // PartState::w: a plain guess (not expected to be a state of the chain)
 
@@ -134,8 +137,8 @@ __device__ __forceinline__ uint32_t part_bits(const PartWin& W, const uint32_t* 
 }
 
 // A block start inside a run of equal widths at or behind frame bit X, or the plain guess.  kPartEvid header bits 1 at stride
-// s = 1 + 12 w from some q in [X + 2048 i, X + 2048 (i + 1)) on -- 32 candidate positions per lane and AND chain, the widths
-// in ascending order, i < kPartSearch -- make (q + kPartSkip * s, w) the state; inside a run of EMPTY blocks (every bit a
+// s = 1 + 12 w from some q in [X, X + 2048 kPartSearch) on -- 32 candidate positions per lane and AND chain, the widths in
+// ascending order, for each of them the range in passes of 2048 positions -- make (q + kPartSkip * s, w) the state; inside a run of EMPTY blocks (every bit a
 // header bit 1) X itself is one.  (Payload bits pass the test with probability 2^-24 per candidate, and the first kPartSkip
 // of the evidence may be a neighbour's bits: a guess is only a guess, k_part_resolve verifies.)
 __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t X, uint32_t limit, uint32_t max_w) {
@@ -145,16 +148,31 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
 #ifdef TRPX_PART_FORCE_WEAK
     return plain;                              // test build (make weakparts): every link is open and goes through k_part_repair
 #endif
-    for (uint32_t pass = 0; pass < kPartSearch; ++pass) {
-        const uint32_t X0 = X + 2048u * pass;
-        if ((uint64_t)X0 + 2048u + (uint64_t)kPartEvid * s_max + 128u > (uint64_t)limit) return plain;   // too close to the frame's end
-        part_fill(W, s_chunk, X0);
-        if (pass == 0u) {
-            const uint32_t a = lane < 4u ? part_bits(W, s_chunk, X0 + 32u * lane) : 0xFFFFFFFFu;
-            if (!__ballot(a != 0xFFFFFFFFu)) return PartState{X, 0u};
-        }
-        for (uint32_t w = 1; w <= max_w; ++w) {
-            const uint32_t s = 1u + (uint32_t)kBlock * w;
+    // the search range and its evidence lie inside one window: [X, X + 2048 kPartSearch + kPartEvid s_max) < 64 K bits
+    static_assert(2048u * kPartSearch + kPartEvid * (1u + 12u * 32u) + 256u < 32u * (uint32_t)kPartChunkDw - 128u, "one window per guess");
+    uint32_t passes = kPartSearch;
+    while (passes && (uint64_t)X + 2048ull * passes + (uint64_t)kPartEvid * s_max + 128u > (uint64_t)limit) --passes;   // too close to the frame's end
+    if (passes == 0u) return plain;
+    part_fill(W, s_chunk, X);
+#ifdef TRPX_PART_NOGUESS
+    return plain;
+#endif
+#ifdef TRPX_PART_MAXW
+    max_w = max_w < TRPX_PART_MAXW ? max_w : TRPX_PART_MAXW;
+#endif
+    {
+        const uint32_t a = lane < 4u ? part_bits(W, s_chunk, X + 32u * lane) : 0xFFFFFFFFu;
+        if (!__ballot(a != 0xFFFFFFFFu)) return PartState{X, 0u};
+    }
+    // widths outside, passes inside: a stream whose runs are short (a change every ten blocks) has no run of kPartEvid blocks in
+    // most passes, and all max_w widths of a pass without a hit cost 30 x what the first pass with a hit does
+    // (widths above 8 get two passes: a cut without a run of a small width in reach is rare, and sweeping every width of a
+    // 32-bit type over the whole range for it cost eight 4096 x 4096 int32 frames 70 of 100 us here)
+    for (uint32_t w = 1; w <= max_w; ++w) {
+        const uint32_t s = 1u + (uint32_t)kBlock * w;
+        const uint32_t passes_w = w <= 8u || passes < 2u ? passes : 2u;
+        for (uint32_t pass = 0; pass < passes_w; ++pass) {
+            const uint32_t X0 = X + 2048u * pass;
             uint32_t a = 0xFFFFFFFFu;
             for (uint32_t k = 0; k < kPartEvid; k += 4u) {                   // (a wrong width's candidates are gone after a dozen bits)
 #pragma unroll

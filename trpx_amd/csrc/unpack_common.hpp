@@ -3,6 +3,7 @@
 // Bit_range::get_range / operator T() (reference include/Bit_pointer.hpp:742-792, :597-617).
 #pragma once
 #include "codec_common.hpp"
+#include <type_traits>
 
 namespace trpx {
 
@@ -320,26 +321,31 @@ __device__ __forceinline__ void unpack_stage_w(const uint32_t (&raw)[4 * RawQuad
 // Every store instruction is executed by all 64 lanes and writes whole 128-byte lines: 3072 bytes as three 16-byte-per-lane
 // stores, 1536 bytes as one 16-byte and one 8-byte-per-lane store, 768 bytes as one 8-byte and one 4-byte-per-lane store (no
 // lane masks, no branches).  skip_line0: the lanes of the first instruction that cover the first line do not store.
-template <typename T>
+template <typename T, bool ALIGNED = true>
 __device__ __forceinline__ void store_group(const uint32_t* __restrict__ staging, T* __restrict__ group_dst, bool skip_line0 = false) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u4l __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2l __attribute__((ext_vector_type(2)));
+    // ALIGNED = false: group_dst is aligned to T only (a frame that starts inside a cache line, stored from its first pixel: the
+    // hardware's unaligned access mode splits the accesses -- what the kernels without a walker beside them do, see store_group_lines)
+    typedef std::conditional_t<ALIGNED, u4l, u4_a1> u4;
+    typedef std::conditional_t<ALIGNED, u2l, u2_a1> u2;
+    typedef std::conditional_t<ALIGNED, uint32_t, u1_a1> u1;
     const int lane = lane_id();
     uint32_t* dst = reinterpret_cast<uint32_t*>(group_dst);
     if constexpr (sizeof(T) == 4) {
         if (!(skip_line0 && lane < 8))
-            __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
+            __builtin_nontemporal_store(reinterpret_cast<const u4l*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
 #pragma unroll
         for (int i = 1; i < 3; ++i)
-            __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[i * kWave + lane], reinterpret_cast<u4*>(dst) + i * kWave + lane);
+            __builtin_nontemporal_store(reinterpret_cast<const u4l*>(staging)[i * kWave + lane], reinterpret_cast<u4*>(dst) + i * kWave + lane);
     } else if constexpr (sizeof(T) == 2) {
         if (!(skip_line0 && lane < 8))
-            __builtin_nontemporal_store(reinterpret_cast<const u4*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
-        __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging + 256)[lane], reinterpret_cast<u2*>(dst + 256) + lane);
+            __builtin_nontemporal_store(reinterpret_cast<const u4l*>(staging)[lane], reinterpret_cast<u4*>(dst) + lane);
+        __builtin_nontemporal_store(reinterpret_cast<const u2l*>(staging + 256)[lane], reinterpret_cast<u2*>(dst + 256) + lane);
     } else {
         if (!(skip_line0 && lane < 16))
-            __builtin_nontemporal_store(reinterpret_cast<const u2*>(staging)[lane], reinterpret_cast<u2*>(dst) + lane);
-        __builtin_nontemporal_store((staging + 128)[lane], dst + 128 + lane);
+            __builtin_nontemporal_store(reinterpret_cast<const u2l*>(staging)[lane], reinterpret_cast<u2*>(dst) + lane);
+        __builtin_nontemporal_store((staging + 128)[lane], reinterpret_cast<u1*>(dst + 128) + lane);
     }
 }
 
@@ -351,9 +357,12 @@ __device__ __forceinline__ void store_group(const uint32_t* __restrict__ staging
 // read them -- dword-aligned LDS reads + one funnel shift per dword when c is no multiple of 4 -- so that every global store
 // instruction writes whole lines at aligned addresses.  The group's last c bytes are left over: a wave's next group, if it
 // follows at once (`cont`), finds them in the head room (`carry_live`); only the two ends of such a run are partial lines
-// (2 bytes per lane).  (Measured, 2000 x (513 x 511) u16: lane-owned rows stored from the frame's first pixel -- every 16-byte
-// store misaligned -- 0.32 ms; line images with the blocks staged at row byte c + ..., i.e. misaligned 8-byte LDS WRITES,
-// 0.36 ms; 512 x 512: 0.22 ms.)
+// (2 bytes per lane).  (Measured, 2000 x (513 x 511) u16, k_decode_frames: lane-owned rows stored from the frame's first pixel --
+// every 16-byte store misaligned -- 0.32 ms; line images with the blocks staged at row byte c + ..., i.e. misaligned 8-byte LDS
+// WRITES, 0.36 ms; this version 0.26 ms; 512 x 512: 0.22 ms.  The kernels WITHOUT a walker beside the extraction waves --
+// k_decode_frames_indexed 0.27 ms, k_unpack_tiles -- are faster with the plain misaligned stores (0.27 against 0.36 ms, 0.126
+// against 0.136 ms for 200 x (1030 x 1065)): there the misaligned stores do not hold up a walker's window loads in the CU's
+// one vector-memory pipeline, and the shifted reads are all cost.)
 constexpr int kStageCarryDw = 32;
 template <int N>                                         // N dwords from LDS byte address `addr` (any 2-byte / 1-byte offset)
 __device__ __forceinline__ void lds_read_shifted(const uint32_t* __restrict__ lds0, uint32_t addr, uint32_t (&out)[N]) {

@@ -122,12 +122,11 @@ __device__ __forceinline__ bool unpack_tile(const uint8_t* __restrict__ terse, u
             if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
             uint32_t* const st = s_stage + kStageCarryDw + wave * unpack_stage_row_dwords<T>();
             T* const gdst = fout + (uint64_t)(b - (uint32_t)lane) * kBlock;
-            const uint32_t gc = (uint32_t)((uintptr_t)gdst & 127u);             // (a wavefront's groups are 256 blocks apart: each is its own run)
             stage_block<T>(st + lane * (kBlock * (int)sizeof(T) / 4), u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            store_group_lines<T>(st, gdst, gc, false, false);
+            store_group<T, false>(st, gdst);                                  // (from the group's first pixel, wherever in a line it lies: store_group_lines)
             __builtin_amdgcn_wave_barrier();                // (the row is rewritten in the next round)
         } else if (nb[r] == kBlock) {
             if (w[r] > (uint32_t)PixelTraits<T>::bits) atomicMax(&status[0], 5u);
