@@ -93,7 +93,7 @@ IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     l.widths = trpx::align_up(8 * n_frames * (size_t)g.n_tiles, 16);
     l.seg = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);   // scratch of trpx_build_index's walk
     l.defer = l.seg + trpx::seg_workspace_bytes(g, n_frames);                 // list of the frames the per-frame walker hands over
-    l.total = l.defer + trpx::align_up(4 * (n_frames + 2), 256);
+    l.total = l.defer + trpx::defer_bytes(n_frames);
     return l;
 }
 struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, parts, part_ws, total; };
@@ -105,7 +105,7 @@ DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     w.widths = trpx::align_up(w.tile_off + 8 * tiles, 16);
     w.seg = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
     w.defer = w.seg + trpx::seg_workspace_bytes(g, n_frames);
-    w.parts = w.defer + trpx::align_up(4 * (n_frames + 2), 256);                // large frames on the per-frame route: the part table
+    w.parts = w.defer + trpx::defer_bytes(n_frames);                            // large frames on the per-frame route: the part table
     const size_t P = trpx::parts_per_frame(g, n_frames);
     w.part_ws = w.parts + (P > 1 ? trpx::align_up(sizeof(trpx::PartDesc) * n_frames * P, 256) : 0);
     w.total = w.part_ws + trpx::part_workspace_bytes(g, n_frames);
@@ -284,7 +284,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
 #else
     constexpr bool no_defer = false;
 #endif
-    a.defer = no_defer ? nullptr : reinterpret_cast<uint32_t*>(ws + w.defer);
+    a.defer = no_defer ? nullptr : reinterpret_cast<uint32_t*>(ws + w.defer + trpx::kDeferFront);
     const int route = g_decode_path;                                          // trpx_set_decode_path / $TRPX_DECODE_PATH
     const bool basic = route == 1, force_tiles = route == 2;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) < 0xF0000000ull;   // 32-bit frame-relative bit offsets
@@ -336,7 +336,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     a.tile_off = reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off);
     a.widths = reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths);
     a.seg_ws = static_cast<char*>(index) + il.seg;
-    a.defer = reinterpret_cast<uint32_t*>(static_cast<char*>(index) + il.defer);
+    a.defer = reinterpret_cast<uint32_t*>(static_cast<char*>(index) + il.defer + trpx::kDeferFront);
     // frames of < 2^26 bits: the per-frame decoder's walker writes the index (the conditions of trpx_decode's per-frame route)
     a.index_per_frame = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) + (1u << 17) < (1ull << 26) && g_decode_path != 2;
     HIP_TRY(trpx::launch_walk_only(a, (uint32_t)(8 * trpx_dtype_size(dtype)), clear_status, static_cast<hipStream_t>(stream)));

@@ -153,5 +153,12 @@ inline void zero_status(uint32_t* status, hipStream_t st) {           // 8 x u32
 // encode: [status-shadow 64 B][frame_size u64 x F][tile_off u64 x F*T][tile_bits u32 x F*T]
 // decode: [tile_off u64 x F*T][widths u8 x F*nblocks (padded to 16)]
 __host__ __device__ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+// The list of the frames the per-frame decoder hands over (DecodeArgs::defer): word 0 = count, words 1 .. n_frames = entries.
+// In FRONT of it (DecodeArgs::defer points at the count): kDeferSlots accumulators of the stack's statistics, one 128-byte line
+// each -- width changes << 32 | blocks, summed over the frames' first super-steps -- by which frames near the hand-over line
+// decide (decode_frame.hip); cleared with the count.
+constexpr uint32_t kDeferSlots = 64, kDeferSlotWords = 16;                 // (u64 words per slot: a cache line)
+constexpr size_t kDeferFront = 8u * kDeferSlots * kDeferSlotWords;         // bytes in front of the list
+inline size_t defer_bytes(size_t n_frames) { return kDeferFront + align_up(4 * (n_frames + 2), 256); }
 
 }  // namespace trpx

@@ -183,6 +183,10 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #ifndef TRPX_DEC_WALK_PRIO
 #define TRPX_DEC_WALK_PRIO 3
 #endif
+#ifndef TRPX_DEFER_NUM                               // hand-over line: more than NUM width changes in DEN blocks
+#define TRPX_DEFER_NUM 2
+#define TRPX_DEFER_DEN 9
+#endif
     if (wave == 0) __builtin_amdgcn_s_setprio(TRPX_DEC_WALK_PRIO);      // the walk is the critical path
     // MODE 1: the widths of the super-step after the one being filled wait in LDS (s_wnext[chunk * 64 + lane]); the filler
     // requests them before it computes and parks them behind -- in registers across the loop they would be live in the
@@ -461,9 +465,31 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     }
                     const uint32_t inc = wave_inclusive_scan(changes);
                     const uint32_t chg = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                    // (2000 x 512^2 u16 with a width change every 2 / 3 / 4 / 5 / 6 blocks, handed over or kept: 0.60 / 0.77 / 0.78 / 0.89 / -
-                    // against 1.25 / 0.85 / 0.67 / 0.55 / 0.47 ms, tools/defer_sweep.py: the line is between 3 and 4)
-                    if (chg * 7u > 2u * per * kWave && lane == 0) s_err = chg * 3u > per * kWave ? 3u : 2u;   // (3: a change every third block and more)
+                    // (2000 x 512^2 u16 frames whose blocks change their width with probability d, runs geometric like detector noise,
+                    // tools/dens_time.py: kept 0.36 / 0.57 / 1.19 / 1.33 ms at d = 0.10 / 0.18 / 0.26 / 0.30 -- steeper than the number
+                    // of steps: the extraction waves share the walker's CU --, handed over 0.72 .. 0.95 ms whatever d: the line is at
+                    // 2 changes in 9 blocks.  Round 3's line, 2 in 7, came from REGULAR patterns, where the walker does better.)
+                    // What a stack must not do is SPLIT: the frames handed over start when the last kept one is through, and their
+                    // walk and extraction take 0.5 ms however few they are -- Poisson(3) counts (d = 0.25) half kept, half not:
+                    // 1.26 ms; d = 0.18 with the line at 2 in 9: a few frames' first 192 blocks read 23 %, 1.11 instead of 0.57 ms.
+                    // So a frame whose own count is within 8 % of the line decides by the STACK's: every frame adds its first
+                    // super-step's counts to one of 64 accumulators (a fire-and-forget atomic each, 64 lines: 4000 same-line atomics
+                    // with their results awaited cost 0.6 ms) and reads their sum.
+                    const uint32_t blk = per * kWave;
+                    uint64_t* const slots = reinterpret_cast<uint64_t*>(defer) - kDeferSlots * kDeferSlotWords;
+                    if (s == 0u && lane == 0)
+                        __hip_atomic_fetch_add(slots + (blockIdx.x % kDeferSlots) * kDeferSlotWords, ((uint64_t)chg << 32) | blk, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    uint64_t d_chg = chg, d_blk = blk;
+                    if (chg * 100u > 14u * blk && chg * 100u < 30u * blk) {
+                        const uint64_t v = __hip_atomic_load(slots + lane * kDeferSlotWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        uint32_t c = (uint32_t)(v >> 32), n = (uint32_t)v;       // (2000 frames x 768 blocks: the sums fit 32 bits per slot and in all)
+                        c = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(c), 63);
+                        n = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n), 63);
+                        if (s == 0u) { d_chg += c; d_blk += n; }                 // (own counts may or may not have arrived: once more or less)
+                        else if (n) { d_chg = c; d_blk = n; }
+                    }
+                    if (d_chg * (uint64_t)TRPX_DEFER_DEN > (uint64_t)TRPX_DEFER_NUM * d_blk && lane == 0) s_err = chg * 3u > blk ? 3u : 2u;   // (3: a change every third block and more -- listed without a search for runs)
                 }
             }
         } else if (s >= 1) {
@@ -707,8 +733,8 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_index
 
 // Writes a.widths / a.tile_off with the per-frame walker; the frames it lists in a.defer are left to launch_seg_listed.
 hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_status, hipStream_t st) {
-    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(a.defer), (uint64_t)1,
-                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0));
+    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(a.defer) - kDeferSlots * kDeferSlotWords,
+                       (uint64_t)(kDeferSlots * kDeferSlotWords + 1), reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0));
     if (max_w <= 8u)
         hipLaunchKernelGGL((k_index_frames<uint8_t>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                            a.frame_offsets, a.geom, a.widths, a.tile_off, a.defer, a.status);
@@ -745,8 +771,10 @@ hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const ui
 template <typename T>
 static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     uint32_t* defer = a.defer && a.seg_ws ? a.defer : nullptr;
-    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(defer), (uint64_t)(defer ? 1 : 0),
-                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)4);   // status block + the deferred-frame count
+    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st,
+                       defer ? reinterpret_cast<uint64_t*>(defer) - kDeferSlots * kDeferSlotWords : static_cast<uint64_t*>(nullptr),
+                       (uint64_t)(defer ? kDeferSlots * kDeferSlotWords + 1 : 0),
+                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)4);   // status block + the deferred-frame count and the stack statistics in front of it
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
