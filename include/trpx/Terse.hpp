@@ -44,6 +44,16 @@ template <typename T> constexpr int out_dtype_of() {
     else if constexpr (std::is_same_v<T, double>) return TRPX_F64;
     else return dtype_of<T>();
 }
+// The header and the library it calls must be of one ABI version (opaque buffer layouts change between versions).
+inline void require_abi() {
+    static const bool ok = [] {
+        if (trpx_abi_version() != TRPX_ABI_VERSION)
+            throw std::runtime_error("libtrpx_hip.so ABI version " + std::to_string(trpx_abi_version()) + " != header's " +
+                                     std::to_string(TRPX_ABI_VERSION));
+        return true;
+    }();
+    (void)ok;
+}
 inline void check(int rc, const char* what) {
     if (rc == TRPX_OK) return;
     std::string msg = std::string(what) + ": " + trpx_last_error_string();
@@ -156,6 +166,7 @@ public:
         // src/prolix.cpp:69-92 calls this once per frame: the compressed stack is uploaded once and kept on the device
         // (trpx_stack_*), a window of frames is expanded per device call, a call normally only copies its frame back
         if (!d_stack) {
+            detail::require_abi();
             std::vector<std::uint64_t> offs(d_frame_sizes.size() + 1, 0);
             for (std::size_t f = 0; f < d_frame_sizes.size(); ++f) offs[f + 1] = offs[f] + d_frame_sizes[f];
             detail::check(trpx_stack_open(&d_stack, d_signed, d_terse_data.data(), d_terse_data.size(), offs.data(), f_states(), d_size,
@@ -262,6 +273,7 @@ private:
 
     template <typename Iterator>
     void f_compress(Iterator data, std::size_t n_frames) {                        // Terse.hpp:500-549 -> device
+        detail::require_abi();
         using V = typename std::iterator_traits<Iterator>::value_type;
         f_drop_stack();
         d_group_states.clear();

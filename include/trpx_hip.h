@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define TRPX_ABI_VERSION 1
+/* 2: the opaque decode index / workspace layouts grew (hand-over list with its statistics, part table); trpx_bench_stream.
+ * A caller compiled against one version must not run against a library of another: size its buffers with THIS library's
+ * trpx_index_bytes / trpx_*_workspace_bytes and compare trpx_abi_version() with TRPX_ABI_VERSION first (the Terse classes do). */
+#define TRPX_ABI_VERSION 2
 
 typedef enum trpx_status {
     TRPX_OK = 0,

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"libtrpx_hip.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "python binding table out of sync with the header"
-    assert L.trpx_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "trpx_hip.h")).read()
+    assert f"#define TRPX_ABI_VERSION {_lib.ABI_VERSION}\n" in hdr and L.trpx_abi_version() == _lib.ABI_VERSION
 
 
 def test_pure_arithmetic_entry_points(oracle):
@@ -147,3 +148,12 @@ def test_integration_md_code_blocks_are_the_compiled_snippets():
             assert ln in doc[at:], (name, ln)
             at = doc.index(ln, at) + 1
     assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "integration_snippets")), "make -C tests/cpp did not build it"
+
+
+def test_kernel_sources_compile_without_the_llvm_testing_option():
+    """decode_frame.hip / encode_fused.hip are built with -mllvm -structurizecfg-skip-uniform-regions=1 (a speed matter: scalar
+    branches stay scalar) around hand-written asm; the sources must stay valid C++ / asm for the compiler's default pipeline
+    too, so that a toolchain without the option still builds a correct library (csrc/Makefile: noflag, toolchain_check)."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "trpx_amd", "csrc"), "noflag"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]

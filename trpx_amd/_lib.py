@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("TRPX_LIB") or os.path.join(_HERE, "libtrpx_hip.so")  
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_CORRUPT, ERR_NO_DEVICE, ERR_TIMEOUT = range(8)
 U8, I8, U16, I16, U32, I32, F32, F64, U64, I64 = range(10)
 STATUS_WORDS = 8
+ABI_VERSION = 2          # TRPX_ABI_VERSION of include/trpx_hip.h (tests/test_abi.py compares them)
 
 
 class TrpxError(RuntimeError):
@@ -97,8 +98,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.trpx_abi_version() != 1:
-            raise ImportError("libtrpx_hip.so ABI version mismatch")
+        if L.trpx_abi_version() != ABI_VERSION:
+            raise ImportError(f"libtrpx_hip.so ABI version {L.trpx_abi_version()} != {ABI_VERSION} (include/trpx_hip.h: TRPX_ABI_VERSION)")
         _lib = L
     return _lib
 
