@@ -211,9 +211,16 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
             if (n_ck < kPartCk && lane == 0) ck[n_ck] = PartCk{pos, w_prev, b};
             n_ck = n_ck < kPartCk ? n_ck + 1u : n_ck;
             ck_next = pos + ck_every;
-            // (a chain that is not the frame's yet may look like anything, for as long as it takes to merge: a tolerant walk is
-            // never stopped -- a frame MOST of whose cuts are plain guesses does not get here, see k_part_walk)
-            if (!tolerant && b - b_ref >= 2048u && (n_exp - exp_ref) * 6u > b - b_ref) { dense = true; break; }
+            // (a chain that is not the frame's yet may look like anything until it has merged: a tolerant walk's count starts
+            // at its sixteenth checkpoint)
+            // (the weakparts test build never stops one: every part there has to get through k_part_repair)
+            if (tolerant && n_ck == 16u) { b_ref = b; exp_ref = n_exp; }
+#ifdef TRPX_PART_FORCE_WEAK
+            constexpr bool stoppable = false;
+#else
+            const bool stoppable = !tolerant || n_ck >= 16u;
+#endif
+            if (stoppable && b - b_ref >= 2048u && (n_exp - exp_ref) * 6u > b - b_ref) { dense = true; break; }
         }
         uint32_t stride = 1u + (uint32_t)kBlock * w_prev;
         {   // the window holds the 64 candidates of a step from here
@@ -400,6 +407,17 @@ __device__ __forceinline__ uint32_t part_rewalk(PartWin& W, uint32_t* __restrict
     return 2u;
 }
 
+// A frame many of whose cuts found no run to start in (run-dominated stacks: one cut in a thousand) is header-dense.
+__device__ __forceinline__ bool part_frame_is_dense(const PartState* __restrict__ sf, uint32_t P) {
+#ifdef TRPX_PART_FORCE_WEAK
+    return false;
+#endif
+    uint32_t n_weak = 0;
+    for (uint32_t q = (uint32_t)lane_id(); q < P; q += kWave) n_weak += (sf[q].w & kPartWeak) != 0u ? 1u : 0u;
+    n_weak = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_weak), 63);
+    return 4u * n_weak > P;
+}
+
 // The frame's cut positions: X_p = p * L.
 __device__ __forceinline__ uint32_t part_len_bits(uint32_t limit, uint32_t P) {
     return (uint32_t)((((uint64_t)limit + P - 1u) / P + 127u) & ~127ull);
@@ -450,14 +468,8 @@ __global__ __launch_bounds__(kWave) void k_part_walk(const uint8_t* __restrict__
     r.flags = 1u;
     PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
     const PartState s = states[(uint64_t)frame * P + p], t = states[(uint64_t)frame * P + p + 1u];
-    // a frame most of whose cuts found no run to start in is header-dense: not worth a walk (it takes the other route)
-    uint32_t n_weak = 0;
-    for (uint32_t q = lane; q < P; q += kWave) n_weak += (states[(uint64_t)frame * P + q].w & kPartWeak) != 0u ? 1u : 0u;
-    n_weak = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_weak), 63);
-#ifdef TRPX_PART_FORCE_WEAK
-    n_weak = 0;
-#endif
-    if (2u * n_weak > P) r.flags = 2u;
+    // a frame a quarter of whose cuts found no run to start in is header-dense: not worth a walk (it takes the other route)
+    if (part_frame_is_dense(states + (uint64_t)frame * P, P)) r.flags = 2u;
     else if (f.ok && t.pos > s.pos && t.pos < f.limit) {
         uint32_t pos = s.pos, w = s.w & ~kPartWeak, cnt = 0, n_ck = 0;
         bool bad = false, dense = false;
@@ -483,7 +495,8 @@ __global__ __launch_bounds__(kWave) void k_part_repair(const uint8_t* __restrict
     const PartWalk prev = walks[wi - 1u], mine = walks[wi];
     const PartState s = states[(uint64_t)frame * P + p], t = states[(uint64_t)frame * P + p + 1u];
     PartFix x{0u, 0u, 0u, 0u};
-    if (prev.flags == 0u && !(prev.o_pos == s.pos && prev.o_w == s.w)) {      // an open link behind a walk that arrived somewhere
+    if (part_frame_is_dense(states + (uint64_t)frame * P, P)) x.state = 3u;  // (the frame takes the other route: see k_part_walk)
+    else if (prev.flags == 0u && !(prev.o_pos == s.pos && prev.o_w == s.w)) { // an open link behind a walk that arrived somewhere
         x.state = 3u;
         if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
         PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
