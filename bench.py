@@ -194,7 +194,10 @@ def main():
     frames = args.frames
     frame0 = rank * frames                                   # C5: GPU g <- frames [2000g, 2000g+2000)
     px = codec.synth(np.uint16, frame0, frames, N_VALUES, device=dev)
+    # one workspace per direction: the encoder's stays the library's between calls (trpx_hip.h, "Workspaces between calls"),
+    # so its descriptor words need no clearing launch in front of every encode
     ws = codec.Workspace(dev)
+    ws_d = codec.Workspace(dev)
     cap = (frames * codec.worst_case_bytes(np.uint16, N_VALUES) + 15) // 16 * 16
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = torch.empty(frames + 1, dtype=torch.int64, device=dev)
@@ -202,8 +205,8 @@ def main():
     st_d = torch.empty(8, dtype=torch.int32, device=dev)
     back = torch.empty((frames, N_VALUES), dtype=torch.uint16, device=dev)
     # size the workspace once (never allocate inside the timed region)
-    ws.get(max(L.trpx_encode_workspace_bytes(_lib.U16, N_VALUES, frames, 12),
-               L.trpx_decode_workspace_bytes(_lib.U16, N_VALUES, frames, 12)))
+    ws.get(L.trpx_encode_workspace_bytes(_lib.U16, N_VALUES, frames, 12))
+    ws_d.get(L.trpx_decode_workspace_bytes(_lib.U16, N_VALUES, frames, 12))
     torch.cuda.synchronize()
 
     # The per-frame size gather (RCCL over xGMI -> global byte offset of every frame) depends only on the encode and
@@ -240,7 +243,7 @@ def main():
                 gather(offs, st_e)
         # decode straight from the device-resident stack (bounded by its worst-case capacity; the
         # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
-        codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+        codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
         if use_dist:
             torch.cuda.current_stream().wait_stream(comm_stream)
         return enc
@@ -304,7 +307,7 @@ def main():
             return e0.elapsed_time(e1) / n
 
         enc_ms = timed(lambda: codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e))
-        dec_ms = timed(lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d))
+        dec_ms = timed(lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws_d, status=st_d))
         # walk-free decode with the encoder's optional decode index (not part of `value`)
         dec_idx_ms = float("nan")
         if not args.headline_only:
@@ -331,7 +334,7 @@ def main():
             return {k: float(np.mean(v)) for k, v in acc.items()}
 
         stage_ms = stages(lambda: codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e),
-                          lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d),
+                          lambda: codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws_d, status=st_d),
                           DEC_STAGES_FRAMES)
         pix_bytes = frames * N_VALUES * 2
         alg_bytes = pix_bytes + total_bytes                    # B_enc = B_dec = N*sizeof(T) + S_f per frame
@@ -389,10 +392,10 @@ def main():
             t_d = timed(lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, index=e4.index), 5)
             assert int(s4[0].item()) == 0 and torch.equal(b4, px4)
             b4.zero_()
-            t_p = timed(lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws), 5)
+            t_p = timed(lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws_d), 5)
             assert int(s4[0].item()) == 0 and torch.equal(b4, px4)
             st4 = stages(lambda: codec.encode(px4, out=e4.data, frame_offsets=e4.frame_offsets, status=e4.status, workspace=ws),
-                         lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws), DEC_STAGES, 5)
+                         lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws_d), DEC_STAGES, 5)
             alg4 = f4 * n4 * 4 + e4.total_bytes()
             c4 = {"workload": f"{f4} frames 4096x4096 int32 synth-v1 (bg -3..3 + sparse peaks < 2^24)",
                   "encode_fps": f4 / t_e * 1e3, "encode_pixel_GBps": f4 * n4 * 4 / t_e / 1e6,
@@ -421,7 +424,7 @@ def main():
         measured = {"read_GBps": stream_GBps(0, pix_bytes), "write_GBps": stream_GBps(1, pix_bytes), "copy_GBps": stream_GBps(2, pix_bytes),
                     "how": "trpx_bench_stream: grid-stride 16 B/lane non-temporal kernels over the stack's pixel bytes, HIP events, 10 launches"}
         # (what the decoder left in `back` was overwritten: restore the headline result for the checks below)
-        codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws, status=st_d)
+        codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
         for r_, kind in ((roofs.get("encode"), "read"), (roofs.get("decode"), "write")):
             if r_:
                 r_["peak_measured"] = measured[kind + "_GBps"]
@@ -443,14 +446,14 @@ def main():
             assert (out[: want.size].cpu().numpy() == want).all(), f"{what}: frame 0 differs from the CPU oracle"
             fo = offs[: nf + 1]
             t_e = timed(lambda: codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e))
-            t_d = timed(lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws, status=st_d))
+            t_d = timed(lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws_d, status=st_d))
             assert int(st_d[0].item()) == 0 and torch.equal(bk.view(torch.int16), pxl.view(torch.int16)), f"{what}: round trip differs"
             bk.zero_()
             en_i = codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e, index=True)
             t_i = timed(lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, status=st_d, index=en_i.index))
             assert int(st_d[0].item()) == 0 and torch.equal(bk.view(torch.int16), pxl.view(torch.int16)), f"{what}: indexed decode differs"
             km = stages(lambda: codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e),
-                        lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws, status=st_d), DEC_STAGES_FRAMES, 5)
+                        lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws_d, status=st_d), DEC_STAGES_FRAMES, 5)
             pb = nf * nv * 2
             alg = pb + nbytes
             return {"workload": what, "frames": nf, "n_values": nv,

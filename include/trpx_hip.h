@@ -183,6 +183,21 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
                     void* pixels_dev, void* stream);
 
 /*
+ * Workspaces between calls.  The single-pass encoder polls and ORs into ~1 MB of descriptor words inside the caller's
+ * workspace that have to be zero when it starts; its last kernel leaves them zero again, and the library REMEMBERS
+ * (device, address, geometry) of the workspaces whose last user, as far as it can know, was such a call, and then skips the
+ * clearing launch in front of the next one (7 us of a 270 us call).  What it cannot see is what others do to that memory,
+ * hence the rule: between two trpx_encode* calls a workspace belongs to the library.  Whoever writes into it, frees it or
+ * hands its address to something else calls trpx_workspace_invalidate(workspace, workspace_bytes) first (NULL, 0: every
+ * workspace the library remembers).  Entry points of this library that are given the memory for another purpose (trpx_decode
+ * with the same workspace, another geometry, the two-pass pipeline) do so by themselves; a call that is captured into a HIP
+ * graph always clears; and the encoder's first tile checks a tag it left in the workspace: a workspace that is not what the
+ * library remembers makes the call report TRPX_ERR_TIMEOUT in the status block, which trpx_encode_checked and the host
+ * wrappers answer with the two-pass pipeline (identical stream, none of these words).  Host-side, thread safe, no device call.
+ */
+int trpx_workspace_invalidate(const void* workspace, size_t workspace_bytes);
+
+/*
  * Measured memory ceilings for the benchmark's roofline block (SURVEY.md section 8 row d): one grid-stride streaming
  * kernel over `bytes` bytes, 16 bytes per lane, non-temporal.  mode 0 = read `src` (dst: a 4-byte device sink),
  * 1 = write `dst`, 2 = copy src -> dst.  Device pointers, 16-byte aligned; stream-ordered.  Bench utility, not codec.

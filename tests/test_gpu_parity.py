@@ -1320,3 +1320,43 @@ print("OK")
 """)
     r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_encoder_workspace_between_calls(gpu, oracle):
+    """The single-pass encoder's descriptor words are cleared by the call's last kernel, and the library skips the clearing
+    launch for a workspace it remembers as clean (include/trpx_hip.h, "Workspaces between calls").  Same workspace call after
+    call, another geometry in between, the decoder given the same memory (the library forgets it by itself), a foreign
+    write announced with trpx_workspace_invalidate -- the stream is the oracle's every time; a foreign write that is NOT
+    announced (here: the whole workspace zeroed, tag included) is caught by the first tile's tag check: the call reports
+    TRPX_ERR_TIMEOUT and Encoded.check() answers with the two-pass pipeline (Terse.hpp:500-549: identical bytes)."""
+    import torch
+    from trpx_amd import codec, _lib
+    L = _lib.lib()
+    n, frames = 512 * 512, 24
+    px = codec.synth(np.uint16, 7, frames, n, device=gpu)
+    want = oracle.encode_stack(px.cpu().numpy())[0]
+    ws = codec.Workspace(gpu)
+
+    def enc(p=px, w=want):
+        e = codec.encode(p, workspace=ws)
+        torch.cuda.synchronize()
+        code = int(e.status[0].item())
+        e.check()
+        assert e.stack().cpu().numpy().tobytes() == w.tobytes()
+        return code
+
+    assert enc() == 0 and enc() == 0 and enc() == 0                       # unknown -> clean -> clean
+    px2 = codec.synth(np.uint16, 90, 5, 300 * 300, device=gpu)             # another geometry in the same memory
+    want2 = oracle.encode_stack(px2.cpu().numpy())[0]
+    assert enc(px2, want2) == 0 and enc() == 0 and enc(px2, want2) == 0 and enc(px2, want2) == 0
+    assert enc() == 0
+    back, st = codec.decode(torch.from_numpy(want).to(gpu), codec.encode(px).frame_offsets, n, frames, np.uint16, workspace=ws)
+    torch.cuda.synchronize()                                               # the decoder scribbles over the same workspace ...
+    assert int(st[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
+    assert enc() == 0 and enc() == 0                                       # ... and the library knows
+    ws.buf.fill_(0xA5)                                                     # a foreign write, announced
+    L.trpx_workspace_invalidate(ws.buf.data_ptr(), ws.buf.numel())
+    assert enc() == 0 and enc() == 0
+    ws.buf.zero_()                                                         # a foreign write, NOT announced: the tag is gone
+    assert enc() == _lib.ERR_TIMEOUT                                       # reported by the first tile; check() re-ran the call (two-pass)
+    assert enc() == 0 and enc() == 0

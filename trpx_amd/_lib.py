@@ -76,6 +76,7 @@ SYMBOLS = {
     "trpx_profile_enable": (_I, [_I]),
     "trpx_profile_read": (_I, [C.POINTER(C.c_float), _I]),
     "trpx_bench_stream": (_I, [_I, _P, _P, _SZ, _P]),
+    "trpx_workspace_invalidate": (_I, [_P, _SZ]),
     "trpx_synth_fill": (_I, [_I, _U64, _U64, _SZ, _SZ, _P, _P]),
     "trpx_header_format": (_SZ, [C.POINTER(trpx_header), C.c_char_p, _SZ]),
     "trpx_header_parse": (_I, [C.c_char_p, _SZ, C.POINTER(trpx_header), C.POINTER(_SZ)]),

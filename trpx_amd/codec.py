@@ -87,8 +87,22 @@ class Workspace:
 
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes:
+            self.release()
             self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self.buf
+
+    def release(self) -> None:
+        """The buffer goes back to torch's allocator, which may hand its address to anything: the library must forget what it
+        remembers about it (trpx_workspace_invalidate: include/trpx_hip.h, "Workspaces between calls")."""
+        if self.buf is not None:
+            try:
+                lib().trpx_workspace_invalidate(self.buf.data_ptr(), self.buf.numel())
+            except Exception:          # (interpreter shutdown)
+                pass
+            self.buf = None
+
+    def __del__(self):
+        self.release()
 
 
 def index_bytes(dtype, n_values: int, n_frames: int, block: int = BLOCK) -> int:

@@ -208,15 +208,18 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     a.idx_widths = index ? reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths) : nullptr;
     if (block != (unsigned)trpx::kBlock || is64(dtype)) {  // any other block size, 64-bit containers: generic (correct-first) kernels
         if (index) return fail(TRPX_ERR_UNSUPPORTED, "trpx_encode_indexed: the decode index needs block=12 and pixels of <= 32 bits");
+        trpx::fused_ws_forget(workspace, workspace_bytes);
         HIP_TRY(trpx::launch_encode_generic(dtype, a, static_cast<hipStream_t>(stream)));
         return TRPX_OK;
     }
     // (frames need not be vector aligned -- most detectors' pixel counts are not multiples of 4: 1030 x 1065, 2463 x 2527 --: the
     // kernels' 16-byte accesses only need what the hardware needs, which in HSA's unaligned access mode is nothing)
     const bool vec_ok = (uint64_t)g.n_blocks * 396 < (1ull << 40);       // frame bits fit the fused encoder's 40-bit accumulator
-    if (g_encode_path == 0 && !t_force_two_pass && vec_ok)
+    if (g_encode_path == 0 && !t_force_two_pass && vec_ok) {
+        trpx::fused_ws_forget(workspace, workspace_bytes, ws + w.fused);   // (a clean descriptor block of another geometry in this memory is no longer)
         HIP_TRY(trpx::launch_encode_fused(dtype, a, ws + w.fused, static_cast<hipStream_t>(stream)));
-    else {
+    } else {
+        trpx::fused_ws_forget(workspace, workspace_bytes);
         HIP_TRY(trpx::launch_encode(dtype, a, static_cast<hipStream_t>(stream)));
         if (index && out)   // the two-pass pipeline does not emit the index: build it from the stream it just wrote
             return build_index_impl(dtype, out, out_capacity, frame_offsets, n_values, n_frames, block, index, status, false, stream);
@@ -266,6 +269,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     if (workspace_bytes < w.total)
         return fail(TRPX_ERR_CAPACITY, "trpx_decode: workspace %zu < %zu", workspace_bytes, w.total);
 
+    trpx::fused_ws_forget(workspace, workspace_bytes);      // (an encoder's clean descriptor words in this memory are about to be overwritten)
     trpx::DecodeArgs a{};
     a.terse = terse;
     a.terse_bytes = terse_bytes;
@@ -447,6 +451,7 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: misaligned pointer");
     const DecWs w = dec_ws(g, n_frames);
     if (workspace_bytes < w.total) return fail(TRPX_ERR_CAPACITY, "trpx_decode_convert: workspace %zu < %zu", workspace_bytes, w.total);
+    trpx::fused_ws_forget(workspace, workspace_bytes);
     trpx::DecodeArgs a{};
     a.terse = terse;
     a.terse_bytes = terse_bytes;
@@ -461,6 +466,11 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
     a.widths = reinterpret_cast<uint8_t*>(ws + w.widths);
     a.seg_ws = ws + w.seg;
     HIP_TRY(trpx::launch_decode_convert(out_dtype, a, stream_signed != 0, frame_offsets != nullptr, static_cast<hipStream_t>(stream)));
+    return TRPX_OK;
+}
+
+int trpx_workspace_invalidate(const void* workspace, size_t workspace_bytes) {
+    trpx::fused_ws_forget(workspace, workspace_bytes);
     return TRPX_OK;
 }
 
@@ -519,6 +529,7 @@ struct Arena {
         hipError_t e = on_device();
         if (e != hipSuccess) return e;
         if (cap[slot] < n) {
+            if (p[slot] && slot == kWorkspace) trpx::fused_ws_forget(p[slot], cap[slot]);
             if (p[slot]) (void)hipFree(p[slot]);
             p[slot] = nullptr; cap[slot] = 0;
             const size_t want = n + n / 8 + 256;             // a little head room: stacks of slightly different sizes reuse it
@@ -537,6 +548,7 @@ struct Arena {
         return hipSuccess;
     }
     void release() {
+        if (p[kWorkspace]) trpx::fused_ws_forget(p[kWorkspace], cap[kWorkspace]);
         for (int i = 0; i < kSlots; ++i) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;

@@ -31,6 +31,8 @@
 #include "encode_kernels.hpp"
 #include "profile.hpp"
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 namespace trpx {
 
@@ -88,7 +90,8 @@ struct SpinGuard {
 
 constexpr uint64_t kStInvalid = 0, kStAgg = 1, kStPrefix = 2;
 constexpr uint32_t kGridY = 32768;                                      // frames per grid.z slice
-constexpr int kWmaxShift = 56;                                           // bnd_pos[tile]: dword index | widest block << 56
+constexpr int kWmaxShift = 56;                                           // bnd_pos[tile]: dword index | head side pending << 55 | widest block << 56
+constexpr uint64_t kBndHead = 1ull << 55;                                // (= the head flag of the boundary's exchange word: k_stitch judges its neighbours by it)
 constexpr uint64_t kHeadFlag = 1ull << 63, kTailFlag = 1ull << 62;   // boundary exchange words (k_encode_fused's end, k_stitch)
 __device__ __forceinline__ uint64_t make_desc(uint64_t st, uint64_t v) { return (st << 62) | (v & ((1ull << 62) - 1)); }
 __device__ __forceinline__ uint64_t desc_status(uint64_t d) { return d >> 62; }
@@ -433,6 +436,8 @@ struct FusedArgs {
     uint64_t* frame_acc;           // [F]        tiles contributed << 40 | bits of the frame so far (atomic adds)
     uint64_t* frame_pref;          // [F]        1 << 63 | inclusive bytes through this frame, once known
     uint64_t* frame_base;          // [F * 16]   1 << 63 | first byte of the frame (one 128-byte line per frame): tile 0 -> the frame's other tiles
+    uint64_t* ws_tag;              // [1]        what the call before this one left behind (see launch_fused_t); checked against expect_tag if that is not 0
+    uint64_t expect_tag;
     uint64_t* frame_offsets;       // [F + 1]    output
     uint32_t* out32;
     uint32_t* status;
@@ -479,6 +484,20 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
     if (frame >= n_frames) return;
     const uint64_t tile = (uint64_t)frame * tpf + t;
     const bool last_tile_of_frame = t + 1 == tpf;
+    if (tile == 0 && tid == 0) {
+        // The stack's first tile clears the status block -- it is dispatched first, and nothing is reported there before a tile
+        // has looked back over the chain that starts with THIS tile's descriptor, which is published behind these stores'
+        // acknowledgement (errors: CAPACITY by the last tile, TIMEOUT after 0.25 s, the tag below by this thread).  The
+        // descriptor words themselves were left cleared by the k_stitch of the call before (launch_fused_t); the tag tells
+        // whether that is still what the workspace holds.
+        karg_ptr kb0 = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        uint64_t* const st64 = reinterpret_cast<uint64_t*>(TRPX_KARG(kb0, status));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st_desc(st64 + i, 0ull);
+        const uint64_t want = TRPX_KARG(kb0, expect_tag);
+        if (want != 0ull && ld_desc(TRPX_KARG(kb0, ws_tag)) != want) atomicMax(&TRPX_KARG(kb0, status)[0], 7u);   // somebody else wrote into the workspace
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const T* fp = pixels + (uint64_t)frame * g.n_values;
     const uint32_t b0 = t * kFusedTileBlocks;
 
@@ -770,7 +789,7 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
                 uint32_t wm = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wm = (s_wfl[i] >> 24) > wm ? (s_wfl[i] >> 24) : wm;
-                TRPX_KARG(kb, bnd_pos)[tile] = (head_pending ? d_first : 0ull) | ((uint64_t)wm << kWmaxShift);
+                TRPX_KARG(kb, bnd_pos)[tile] = (head_pending ? d_first | kBndHead : 0ull) | ((uint64_t)wm << kWmaxShift);
             }
             if (carry_out) s_carry = tail_bits;                              // this phase's share of dword d_last -> next image
             else if ((q_end & 31) != 0 && (completed_first || !head_pending)) {   // our share of dword d_last
@@ -856,14 +875,25 @@ __global__ __launch_bounds__(kThreads, fused_occupancy<T>()) void k_encode_fused
 
 // Stores every dword that two (or, with tiny tiles, more) tiles share: the OR of what they deposited.  Also reduces the
 // tiles' widest-block values into status[1] (d_prolix_bits, Terse.hpp:516): one atomic per workgroup.
-__global__ __launch_bounds__(kThreads) void k_stitch(const uint64_t* __restrict__ xw, const uint64_t* __restrict__ pos,
-                                                     uint64_t n_tiles, uint32_t* __restrict__ out32, uint64_t out_capacity,
-                                                     uint32_t* __restrict__ status) {
+// And it leaves the workspace as the NEXT call needs it: every descriptor word this call polled or OR-ed into is cleared
+// again -- by the thread that read it last: a run of boundaries inside one dword is read and cleared by its first boundary's
+// thread alone, which the others tell from bnd_pos (never from a neighbour's exchange word) -- and the tag is set.  A call
+// that reported an error (a tile that gave up leaves no bnd_pos) clears everything and stitches nothing.
+__global__ __launch_bounds__(kThreads) void k_stitch(uint64_t* __restrict__ tile_desc, uint64_t* __restrict__ xw, const uint64_t* __restrict__ pos,
+                                                     uint64_t n_tiles, uint64_t* __restrict__ frame_words, uint64_t n_frame_words,
+                                                     uint64_t* __restrict__ ws_tag, uint64_t tag, uint32_t* __restrict__ out32,
+                                                     uint64_t out_capacity, uint32_t* __restrict__ status) {
     __shared__ uint32_t s_max[4];
     const uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x;     // tile b; boundary b = between tile b-1 and tile b
-    constexpr uint64_t kPosMask = (1ull << kWmaxShift) - 1;
-    const uint64_t pw = b < n_tiles ? pos[b] : 0ull;
-    const uint32_t wm = wave_max((uint32_t)(pw >> kWmaxShift));
+    constexpr uint64_t kPosMask = kBndHead - 1;
+    // (everything this thread may need is requested at once: the kernel is a handful of round trips, not work)
+    const bool in = b < n_tiles;
+    const uint32_t st0 = __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t pw = in ? pos[b] : 0ull;
+    const uint64_t pb = in && b > 0 ? pos[b - 1] : 0ull;
+    const uint64_t xb = in ? xw[b] : 0ull;
+    const bool failed = st0 != 0u;
+    const uint32_t wm = wave_max(failed ? 0u : (uint32_t)(pw >> kWmaxShift));
     if (lane_id() == 0) s_max[wave_id()] = wm;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -871,13 +901,22 @@ __global__ __launch_bounds__(kThreads) void k_stitch(const uint64_t* __restrict_
         for (int i = 1; i < 4; ++i) m = s_max[i] > m ? s_max[i] : m;
         if (m) atomicMax(&status[1], m);
     }
-    if (b == 0 || b >= n_tiles) return;
-    const uint64_t w = xw[b];
-    if (!(w & kHeadFlag)) return;                                         // dword-aligned boundary: nothing shared
+    for (uint64_t i = b; i < n_frame_words; i += (uint64_t)gridDim.x * kThreads) frame_words[i] = 0ull;
+    if (b == 0) ws_tag[0] = tag;
+    if (b >= n_tiles) return;
+    tile_desc[b] = 0ull;
+    if (failed || b == 0) { xw[b] = 0ull; return; }
+    if (!(pw & kBndHead)) { xw[b] = 0ull; return; }                      // dword-aligned boundary: nothing shared (and nothing deposited)
     const uint64_t d = pw & kPosMask;
-    if ((xw[b - 1] & kHeadFlag) && (pos[b - 1] & kPosMask) == d && b > 1) return;   // middle of a run (tiny tiles): its first boundary stores
-    uint32_t acc = (uint32_t)w;
-    for (uint64_t k = b + 1; k < n_tiles && (xw[k] & kHeadFlag) && (pos[k] & kPosMask) == d; ++k) acc |= (uint32_t)xw[k];
+    if (b > 1 && (pb & kBndHead) && (pb & kPosMask) == d) return;         // middle of a run (tiny tiles): its first boundary stores and clears
+    uint32_t acc = (uint32_t)xb;
+    xw[b] = 0ull;
+    for (uint64_t k = b + 1; k < n_tiles; ++k) {
+        const uint64_t pk = pos[k];
+        if (!((pk & kBndHead) && (pk & kPosMask) == d)) break;
+        acc |= (uint32_t)xw[k];
+        xw[k] = 0ull;
+    }
     if (4 * d + 4 <= out_capacity) out32[d] = acc;
 }
 
@@ -889,7 +928,33 @@ static uint32_t fused_tiles_per_frame(const FrameGeom& g) {
 
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     const size_t tpf = ((size_t)g.n_blocks + 2 * kThreads - 1) / (2 * kThreads);   // finest tiling (32-bit pixels)
-    return align_up(8 * (3 * n_frames * tpf + 18 * n_frames), 256) + 64 * n_frames * tpf;   // + diagnostic stamps
+    return align_up(8 * (3 * n_frames * tpf + 18 * n_frames + 1), 256) + 64 * n_frames * tpf;   // + the tag + diagnostic stamps
+}
+
+// ---- workspaces the library knows to be clean ---------------------------------------------------------------------------------
+// k_encode_fused polls and ORs into ~1 MB of descriptor words that have to be zero when it starts.  Clearing them took a launch
+// of its own in front of every call (k_zero_words: 7 us of a 270 us call, launch latency, not work).  Now the call's LAST kernel,
+// k_stitch, leaves every word it or the encoder used cleared again and writes a tag; the library remembers (device, address,
+// geometry, tag) of the workspaces whose last user, as far as it knows, was such a call, and skips the clearing launch for
+// them.  What it cannot know is what others did to the memory in between, hence the rules (include/trpx_hip.h): a workspace
+// is the library's between calls -- whoever writes into it, frees it or hands the address to something else calls
+// trpx_workspace_invalidate -- every entry point of this library that is given a workspace for another purpose forgets it by
+// itself, a call that is being captured into a graph always clears (a replay does not pass through here), and the encoder's
+// first tile compares the tag: a workspace that is not what the library remembers makes the call report TRPX_ERR_TIMEOUT -- the
+// status the checked entry points answer with the two-pass pipeline, which uses none of these words.
+namespace {
+struct CleanWs { int device; const void* ptr; uint64_t sig, tag; };
+std::mutex g_clean_mu;
+std::vector<CleanWs> g_clean;                                             // a handful of entries: linear search
+uint64_t g_next_tag = 0x5452505800000001ull;
+}  // namespace
+void fused_ws_forget(const void* lo, size_t bytes, const void* keep) {
+    std::lock_guard<std::mutex> lk(g_clean_mu);
+    const char* a = static_cast<const char*>(lo);
+    for (size_t i = 0; i < g_clean.size();) {
+        const char* p = static_cast<const char*>(g_clean[i].ptr);
+        if (p != keep && (!lo || (p >= a && p < a + bytes))) { g_clean[i] = g_clean.back(); g_clean.pop_back(); } else ++i;
+    }
 }
 
 template <typename T>
@@ -911,27 +976,53 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     a.status = e.status;
     a.idx_widths = e.idx_widths;
     a.idx_group_off = e.idx_group_off;
-    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + 18 * e.n_frames), 256));
+    a.ws_tag = a.frame_base + 16 * (size_t)e.n_frames;
+    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + 18 * e.n_frames + 1), 256));
 #ifdef TRPX_DIAGNOSTICS
     a.debug = getenv("TRPX_FUSED_DEBUG") ? (uint32_t)atoi(getenv("TRPX_FUSED_DEBUG")) : 0u;
 #else
     a.debug = 0u;
 #endif
+    // Is the workspace known to be clean (see above)?  Never while the stream is being captured.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+    int device = -1;
+    (void)hipGetDevice(&device);
+    const uint64_t sig = ((uint64_t)sizeof(T) << 56) ^ ((uint64_t)a.tiles_per_frame << 32) ^ (uint64_t)e.n_frames ^ ((uint64_t)e.geom.n_blocks << 8);
+    uint64_t expect = 0, tag;
+    {
+        std::lock_guard<std::mutex> lk(g_clean_mu);
+        tag = g_next_tag++;
+        for (size_t i = 0; i < g_clean.size(); ++i)
+            if (g_clean[i].device == device && g_clean[i].ptr == ws) {
+                if (g_clean[i].sig == sig && cap == hipStreamCaptureStatusNone) expect = g_clean[i].tag;
+                g_clean[i] = g_clean.back(); g_clean.pop_back();            // (re-entered below if this call leaves it clean)
+                break;
+            }
+    }
+    a.expect_tag = expect;
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    // every polled / OR-ed word and the status block, cleared on every call (see k_zero_words)
-    hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
-                       (uint64_t)(3 * tiles + 18 * e.n_frames), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
+    if (expect == 0)   // unknown workspace: every polled / OR-ed word, the tag and the status block (a kernel, not a memset node: see k_zero_words)
+        hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
+                           (uint64_t)(3 * tiles + 18 * e.n_frames + 1), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
     prof.mark(st);
     hipLaunchKernelGGL((k_encode_fused<T>), dim3(a.tiles_per_frame, e.n_frames < kGridY ? e.n_frames : kGridY, (e.n_frames + kGridY - 1) / kGridY),
                        dim3(kThreads), 0, st,
                        static_cast<const T*>(e.pixels), a);
     prof.mark(st);
     hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                       a.tail_desc, a.bnd_pos, (uint64_t)tiles, a.out32, (uint64_t)e.out_capacity, a.status);
+                       a.tile_desc, a.tail_desc, static_cast<const uint64_t*>(a.bnd_pos), (uint64_t)tiles, a.frame_acc, (uint64_t)(18 * (size_t)e.n_frames),
+                       a.ws_tag, tag, a.out32, (uint64_t)e.out_capacity, a.status);
     prof.mark(st);
-    return hipGetLastError();
+    const hipError_t err = hipGetLastError();
+    if (err == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        std::lock_guard<std::mutex> lk(g_clean_mu);
+        if (g_clean.size() >= 64) g_clean.erase(g_clean.begin());
+        g_clean.push_back(CleanWs{device, ws, sig, tag});
+    }
+    return err;
 }
 
 hipError_t launch_encode_fused(int dtype, const EncodeArgs& e, void* ws, hipStream_t st) {

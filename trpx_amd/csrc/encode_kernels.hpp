@@ -67,6 +67,8 @@ hipError_t launch_encode_generic(int dtype, const EncodeArgs& a, hipStream_t st)
 // single-pass encoder (encode_fused.hip); `ws` = fused_workspace_bytes() of descriptor words
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_encode_fused(int dtype, const EncodeArgs& a, void* ws, hipStream_t st);
+// the library's memory of workspaces its single-pass encoder left clean: forget those inside [lo, lo + bytes) (lo == nullptr: all)
+void fused_ws_forget(const void* lo, size_t bytes, const void* keep = nullptr);
 hipError_t launch_decode(int dtype, const DecodeArgs& a, bool have_offsets, hipStream_t st);
 // converting decode (decode.hip): any integral output type with clamping, float, double; stream signedness given
 hipError_t launch_decode_convert(int dtype, const DecodeArgs& a, int stream_signed, bool have_offsets, hipStream_t st);
