@@ -36,11 +36,12 @@
 // HBM traffic: the stream once more (walk only: no pixels), 0.2 of the algorithmic bytes of a u16 stack.
 #include "codec_common.hpp"
 #include "encode_kernels.hpp"
+#include <stdlib.h>
 
 namespace trpx {
 
 constexpr int kPartChunkDw = 2048;             // the walker's stream window: 8 KB
-constexpr uint32_t kPartEvid = 24;             // header bits of evidence for a start inside a run
+constexpr uint32_t kPartEvid = 32;             // header bits of evidence for a start inside a run: a stack has thousands of cuts x 10^5 candidates each, and with 24 bits one guess per stack WAS wrong -- on a chain that, in run-dominated data, does not merge before its part ends (the frame then takes the other route: +4 ms)
 constexpr uint32_t kPartSkip = 12;             // the start lies this many blocks inside the evidence (the bits in front of a run are 1 half the time)
 #ifndef TRPX_PART_SEARCH
 #define TRPX_PART_SEARCH 8
@@ -66,8 +67,14 @@ struct PartFix {                               // what k_part_repair leaves per 
 uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames) {
     if (g.n_blocks <= kPartMaxBlocks || n_frames == 0) return 1u;
     // enough parts to fill the GPU one and a half times over (8 workgroups per CU), of 4 K .. 16 K blocks
-    const uint64_t p_min = (g.n_blocks + kPartBlocks - 1u) / kPartBlocks, p_max = g.n_blocks / 4096u;
-    const uint64_t p_want = (3072u + n_frames - 1u) / n_frames;
+#ifdef TRPX_DIAGNOSTICS
+    static const uint64_t want_total = getenv("TRPX_PART_TOTAL") ? (uint64_t)atoi(getenv("TRPX_PART_TOTAL")) : 3072u;
+    static const uint64_t min_blocks = getenv("TRPX_PART_MIN") ? (uint64_t)atoi(getenv("TRPX_PART_MIN")) : 4096u;
+#else
+    constexpr uint64_t want_total = 3072u, min_blocks = 4096u;
+#endif
+    const uint64_t p_min = (g.n_blocks + kPartBlocks - 1u) / kPartBlocks, p_max = g.n_blocks / min_blocks;
+    const uint64_t p_want = (want_total + n_frames - 1u) / n_frames;
     const uint64_t hi = p_max > p_min ? p_max : p_min;
     const uint64_t P = p_want < p_min ? p_min : (p_want > hi ? hi : p_want);
     return (uint32_t)P;
@@ -139,7 +146,7 @@ __device__ __forceinline__ uint32_t part_bits(const PartWin& W, const uint32_t* 
 // A block start inside a run of equal widths at or behind frame bit X, or the plain guess.  kPartEvid header bits 1 at stride
 // s = 1 + 12 w from some q in [X, X + 2048 kPartSearch) on -- 32 candidate positions per lane and AND chain, the widths in
 // ascending order, for each of them the range in passes of 2048 positions -- make (q + kPartSkip * s, w) the state; inside a run of EMPTY blocks (every bit a
-// header bit 1) X itself is one.  (Payload bits pass the test with probability 2^-24 per candidate, and the first kPartSkip
+// header bit 1) X itself is one.  (Payload bits pass the test with probability 2^-32 per candidate, and the first kPartSkip
 // of the evidence may be a neighbour's bits: a guess is only a guess, k_part_resolve verifies.)
 __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t X, uint32_t limit, uint32_t max_w) {
     const uint32_t lane = (uint32_t)lane_id();
@@ -475,8 +482,10 @@ __global__ __launch_bounds__(kWave) void k_part_walk(const uint8_t* __restrict__
         bool bad = false, dense = false;
         const uint32_t span = t.pos - s.pos;
         const uint32_t every = span / (kPartCk - 8u) > 4096u ? span / (kPartCk - 8u) : 4096u;
+        // (only the frame's first part is known to start on the frame's chain: a run guess can be wrong too -- one in a few
+        // thousand was, with 24 bits of evidence -- and its walk then has to get to the merge like a plain guess's)
         part_walk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cnt, bad, dense, cks + (uint64_t)blockIdx.x * kPartCk, every, n_ck,
-                  (s.w & kPartWeak) != 0u);
+                  p != 0u);
         r.o_pos = pos; r.o_w = w; r.cnt = cnt; r.n_ck = n_ck; r.flags = (bad ? 1u : 0u) | (dense ? 2u : 0u);
     }
     if (lane == 0) walks[blockIdx.x] = r;
