@@ -1360,3 +1360,27 @@ def test_encoder_workspace_between_calls(gpu, oracle):
     ws.buf.zero_()                                                         # a foreign write, NOT announced: the tag is gone
     assert enc() == _lib.ERR_TIMEOUT                                       # reported by the first tile; check() re-ran the call (two-pass)
     assert enc() == 0 and enc() == 0
+
+
+@pytest.mark.parametrize("dtype,lo,hi", [(np.uint16, 100, 108), (np.int32, 1000, 1024), (np.uint8, 192, 200), (np.int16, -300, -290)])
+def test_large_frames_with_a_pedestal(gpu, oracle, dtype, lo, hi):
+    """Raw detector counts sit on a pedestal: every pixel in [lo, hi).  Their constant payload bits pass the run test of the
+    part cuts (decode_part.hip: header bits 1 at the run's stride) like header bits do, at twelve positions per constant bit
+    and stride; the cuts have to tell the header among them (part_header_phase), or the frame must take another route and
+    still decode exactly.  One run-dominated frame and one with a sprinkling of outliers per type."""
+    import torch
+    from trpx_amd import codec
+    rng = np.random.RandomState(11)
+    n, frames = 1030 * 1065 + 7, 5
+    a = rng.randint(lo, hi, (frames, n)).astype(dtype)
+    a[1::2, rng.randint(0, n, 300)] = lo + (hi - lo) * 3                   # outliers: explicit headers every few thousand blocks
+    px = torch.from_numpy(a).to(gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    want, _ = oracle.encode(a[1])
+    o = enc.frame_offsets.cpu().numpy()
+    assert enc.stack()[int(o[1]): int(o[2])].cpu().numpy().tobytes() == want.tobytes()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0 and torch.equal(back, px)

@@ -49,6 +49,7 @@ constexpr uint32_t kPartSkip = 12;             // the start lies this many block
 constexpr uint32_t kPartSearch = TRPX_PART_SEARCH;   // passes of 2048 candidate positions behind X_p
 constexpr uint32_t kPartCk = 256;              // checkpoints per part
 constexpr uint32_t kPartWeak = 0x80000000u;    // PartState::w: a plain guess (not expected to be a state of the chain)
+constexpr uint32_t kPartAmbig = 0x40000000u;   //   ... because runs were found, but not which of their passing positions is the header's
 
 struct PartState { uint32_t pos, w; };
 struct PartCk { uint32_t pos, w, cnt; };
@@ -148,7 +149,57 @@ __device__ __forceinline__ uint32_t part_bits(const PartWin& W, const uint32_t* 
 // ascending order, for each of them the range in passes of 2048 positions -- make (q + kPartSkip * s, w) the state; inside a run of EMPTY blocks (every bit a
 // header bit 1) X itself is one.  (Payload bits pass the test with probability 2^-32 per candidate, and the first kPartSkip
 // of the evidence may be a neighbour's bits: a guess is only a guess, k_part_resolve verifies.)
-__device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t X, uint32_t limit, uint32_t max_w) {
+//
+// Pixels with a pedestal (raw detector counts: every value in 100 .. 107, say) have CONSTANT payload bits, and those pass the
+// test at the run's own stride just like its header bits: the first passing position is then a payload bit's more often than
+// not, a chain started there stays beside the frame's for as long as the run lasts, and every cut of every frame is wrong the
+// same way.  But the passing positions of one stride are a header's plus, for every constant bit b of the pixels, the twelve
+// positions header + 1 + b + j w of that bit in the block's twelve fields: the header is the one passing position relative to
+// which all the others fall into complete classes of twelve (part_header_phase; one passing position per stride, the case
+// without a pedestal, needs no such test).
+__device__ __forceinline__ bool part_pm_bit(const uint32_t* __restrict__ pm, uint32_t i) { return ((pm[i >> 5] >> (i & 31u)) & 1u) != 0u; }
+
+// pm: pass bits of 2048 consecutive positions; r0: the first passing one; s, w: the stride and its width.  Returns the index of
+// the header among the passing positions in [r0, r0 + s), or ~0 if that cannot be told (fewer than s positions left, no or
+// several consistent ones).
+__device__ __forceinline__ uint32_t part_header_phase(const uint32_t* __restrict__ pm, uint32_t r0, uint32_t s, uint32_t w) {
+    const uint32_t lane = (uint32_t)lane_id();
+    if (r0 + 2u * s > 2048u) return ~0u;
+    uint32_t n = 0;
+    for (uint32_t i = lane; i < s; i += kWave) n += part_pm_bit(pm, r0 + i) ? 1u : 0u;
+    n = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n), 63);
+    if (n == 1u) return r0;
+    if (n % 12u != 1u) return ~0u;
+    uint32_t found = ~0u, n_found = 0;
+    for (uint32_t base = 0; base < s; base += kWave) {
+        const uint32_t c = base + lane;                                        // candidate header: position r0 + c
+        bool ok = c < s && part_pm_bit(pm, r0 + c);
+        // (the grid of twelve fields may be shifted along a run of constant bits and still fit -- constant bits 5 and 6 of 7 read
+        // as {0, 6} one position to the left, as {0, 1} two --: a pedestal's constant bits are the TOP ones, w - k .. w - 1, and
+        // only the candidate whose complete classes are exactly such a run counts.  `top` = length of the run of complete classes
+        // that ends at bit w - 1.)
+        uint32_t classes = 0, top = 0;
+        for (uint32_t b = 0; b < w && __ballot(ok); ++b) {
+            uint32_t cnt = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)kBlock; ++j) {
+                uint32_t o = c + 1u + b + j * w;                               // < 2 s
+                o = o >= s ? o - s : o;
+                cnt += ok && part_pm_bit(pm, r0 + o) ? 1u : 0u;
+            }
+            ok = ok && (cnt == 0u || cnt == (uint32_t)kBlock);
+            classes += cnt == (uint32_t)kBlock ? 1u : 0u;
+            top = cnt == (uint32_t)kBlock ? top + 1u : 0u;
+        }
+        ok = ok && 1u + (uint32_t)kBlock * classes == n && top == classes;
+        const uint64_t m = __ballot(ok);
+        if (m) { n_found += (uint32_t)__builtin_popcountll(m); found = r0 + base + (uint32_t)__builtin_ctzll(m); }
+    }
+    return n_found == 1u ? found : ~0u;
+}
+
+__device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t* __restrict__ s_pm, uint32_t X, uint32_t limit,
+                                                uint32_t max_w) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t s_max = 1u + (uint32_t)kBlock * max_w;
     const PartState plain{X, kPartWeak};
@@ -175,6 +226,7 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
     // most passes, and all max_w widths of a pass without a hit cost 30 x what the first pass with a hit does
     // (widths above 8 get two passes: a cut without a run of a small width in reach is rare, and sweeping every width of a
     // 32-bit type over the whole range for it cost eight 4096 x 4096 int32 frames 70 of 100 us here)
+    bool ambiguous = false;
     for (uint32_t w = 1; w <= max_w; ++w) {
         const uint32_t s = 1u + (uint32_t)kBlock * w;
         const uint32_t passes_w = w <= 8u || passes < 2u ? passes : 2u;
@@ -190,11 +242,19 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
             if (hits) {
                 const int l0 = __builtin_ctzll(hits);
                 const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, l0);
-                return PartState{X0 + 32u * (uint32_t)l0 + (uint32_t)__builtin_ctz(a0) + kPartSkip * s, w};
+                const uint32_t r0 = 32u * (uint32_t)l0 + (uint32_t)__builtin_ctz(a0);
+                __builtin_amdgcn_wave_barrier();
+                s_pm[lane] = a;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t h = part_header_phase(s_pm, r0, s, w);
+                if (h != ~0u) return PartState{X0 + h + kPartSkip * s, w};
+                ambiguous = true;               // (cannot tell the header here: the range's later passes, then other widths)
             }
         }
     }
-    return plain;
+    return ambiguous ? PartState{X, kPartWeak | kPartAmbig} : plain;
 }
 
 // Walks the chain from (pos, w) and counts the blocks that start in front of frame bit T; leaves the state at the first block
@@ -414,15 +474,21 @@ __device__ __forceinline__ uint32_t part_rewalk(PartWin& W, uint32_t* __restrict
     return 2u;
 }
 
-// A frame many of whose cuts found no run to start in (run-dominated stacks: one cut in a thousand) is header-dense.
-__device__ __forceinline__ bool part_frame_is_dense(const PartState* __restrict__ sf, uint32_t P) {
+// A frame many of whose cuts found no run to start in (run-dominated stacks: one cut in a thousand) is header-dense: 1; one
+// many of whose cuts found runs but not the headers in them is run-dominated with a problem (part_header_phase): 2; else 0.
+__device__ __forceinline__ uint32_t part_frame_kind(const PartState* __restrict__ sf, uint32_t P) {
 #ifdef TRPX_PART_FORCE_WEAK
-    return false;
+    return 0u;
 #endif
-    uint32_t n_weak = 0;
-    for (uint32_t q = (uint32_t)lane_id(); q < P; q += kWave) n_weak += (sf[q].w & kPartWeak) != 0u ? 1u : 0u;
+    uint32_t n_weak = 0, n_amb = 0;
+    for (uint32_t q = (uint32_t)lane_id(); q < P; q += kWave) {
+        const uint32_t w = sf[q].w;
+        n_weak += (w & kPartWeak) != 0u && (w & kPartAmbig) == 0u ? 1u : 0u;
+        n_amb += (w & kPartAmbig) != 0u ? 1u : 0u;
+    }
     n_weak = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_weak), 63);
-    return 4u * n_weak > P;
+    n_amb = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_amb), 63);
+    return 4u * n_weak > P ? 1u : (4u * n_amb > P ? 2u : 0u);
 }
 
 // The frame's cut positions: X_p = p * L.
@@ -452,13 +518,15 @@ __global__ __launch_bounds__(kWave) void k_part_guess(const uint8_t* __restrict_
                                                       const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
                                                       PartState* __restrict__ states) {
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    __shared__ uint32_t s_pm[kWave + 2];
     const uint32_t frame = blockIdx.x / P, p = blockIdx.x % P;
     const uint32_t lane = (uint32_t)lane_id();
     if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    if (lane < 2u) s_pm[kWave + lane] = 0u;
     PartState s{0u, 0u};                                                      // a frame starts at bit 0 with width 0 (Terse.hpp:359, :505)
     if (p != 0u) {
         PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
-        s = f.ok ? part_guess(f.W, s_chunk, p * f.L, f.limit, max_w) : PartState{0u, kPartWeak};
+        s = f.ok ? part_guess(f.W, s_chunk, s_pm, p * f.L, f.limit, max_w) : PartState{0u, kPartWeak};
     }
     if (lane == 0) states[blockIdx.x] = s;
 }
@@ -476,9 +544,10 @@ __global__ __launch_bounds__(kWave) void k_part_walk(const uint8_t* __restrict__
     PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
     const PartState s = states[(uint64_t)frame * P + p], t = states[(uint64_t)frame * P + p + 1u];
     // a frame a quarter of whose cuts found no run to start in is header-dense: not worth a walk (it takes the other route)
-    if (part_frame_is_dense(states + (uint64_t)frame * P, P)) r.flags = 2u;
+    const uint32_t kind = part_frame_kind(states + (uint64_t)frame * P, P);
+    if (kind) r.flags = kind == 1u ? 2u : 4u;                               // (4: not dense, but not worth a walk either)
     else if (f.ok && t.pos > s.pos && t.pos < f.limit) {
-        uint32_t pos = s.pos, w = s.w & ~kPartWeak, cnt = 0, n_ck = 0;
+        uint32_t pos = s.pos, w = s.w & ~(kPartWeak | kPartAmbig), cnt = 0, n_ck = 0;
         bool bad = false, dense = false;
         const uint32_t span = t.pos - s.pos;
         const uint32_t every = span / (kPartCk - 8u) > 4096u ? span / (kPartCk - 8u) : 4096u;
@@ -504,7 +573,19 @@ __global__ __launch_bounds__(kWave) void k_part_repair(const uint8_t* __restrict
     const PartWalk prev = walks[wi - 1u], mine = walks[wi];
     const PartState s = states[(uint64_t)frame * P + p], t = states[(uint64_t)frame * P + p + 1u];
     PartFix x{0u, 0u, 0u, 0u};
-    if (part_frame_is_dense(states + (uint64_t)frame * P, P)) x.state = 3u;  // (the frame takes the other route: see k_part_walk)
+    // a frame a quarter of whose links are open has a systematic problem with its cuts (see k_part_resolve: pedestals): counting
+    // every part again from its neighbour's end state would be a second walk of the frame for nothing
+    uint32_t n_open = 0;
+    for (uint32_t q = 1u + lane; q + 1u < P; q += kWave) {
+        const PartWalk wq = walks[(uint64_t)frame * (P - 1u) + q - 1u];
+        const PartState sq = states[(uint64_t)frame * P + q];
+        n_open += wq.flags == 0u && !(wq.o_pos == sq.pos && wq.o_w == sq.w) ? 1u : 0u;
+    }
+    n_open = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_open), 63);
+#ifdef TRPX_PART_FORCE_WEAK
+    n_open = 0;
+#endif
+    if (part_frame_kind(states + (uint64_t)frame * P, P) != 0u || 4u * n_open > P) x.state = 3u;   // (the frame takes another route)
     else if (prev.flags == 0u && !(prev.o_pos == s.pos && prev.o_w == s.w)) { // an open link behind a walk that arrived somewhere
         x.state = 3u;
         if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
@@ -522,6 +603,7 @@ __global__ __launch_bounds__(kWave) void k_part_repair(const uint8_t* __restrict
 // See the head of the file.  list[0] = count, list[1 + i] = frame | (dense: bit 31).
 __global__ __launch_bounds__(kWave) void k_part_resolve(const PartState* __restrict__ states, const PartWalk* __restrict__ walks,
                                                         const PartFix* __restrict__ fixes, FrameGeom g, uint32_t P,
+                                                        const uint64_t* __restrict__ frame_offsets, uint64_t terse_bytes,
                                                         PartDesc* __restrict__ parts, uint32_t* __restrict__ list,
                                                         uint32_t* __restrict__ status) {
     const uint32_t frame = blockIdx.x, lane = (uint32_t)lane_id();
@@ -545,7 +627,7 @@ __global__ __launch_bounds__(kWave) void k_part_resolve(const PartState* __restr
             if (p > 0u) x = xf[p];
             good = r.flags == 0u;
             if (p == 0u || x.state == 0u) {                                   // starts in its guess: S_0, or the link in front of it is closed
-                st = PartState{s.pos, s.w & ~kPartWeak}; en = PartState{r.o_pos, r.o_w}; cnt = r.cnt;
+                st = PartState{s.pos, s.w & ~(kPartWeak | kPartAmbig)}; en = PartState{r.o_pos, r.o_w}; cnt = r.cnt;
             } else {
                 const PartWalk q = wf[p - 1u];
                 st = PartState{q.o_pos, q.o_w};
@@ -585,10 +667,22 @@ __global__ __launch_bounds__(kWave) void k_part_resolve(const PartState* __restr
         if (running >= g.n_blocks) ok = false;                                // (the last part holds at least the frame's last block)
     }
     if (ok && g.n_blocks - running > kPartMaxBlocks) ok = false;
-    if (!ok) {                                                                // the whole frame takes the other route
+    if (!ok) {
+        // No part table for this frame.  Header-dense: the position-parallel walk + tiled extraction (the list).  Otherwise --
+        // run-dominated, but the cuts did not work out: e.g. pixels with a pedestal, whose constant payload bits look like
+        // header bits at the same stride, so that every cut starts beside the chain and stays there -- the frame is ONE unit for
+        // its one workgroup's serial walker, as before there were parts (0.4 ms for 200 frames of 1030 x 1065 against 2.9 ms on
+        // the list's route), provided its bits fit the decoder's 26-bit positions.
+        const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+        const bool one_unit = !dense && fe > fo && fe <= terse_bytes && 8 * (fe - fo) + (1u << 17) < (1ull << 26);
         __builtin_amdgcn_s_waitcnt(0);
-        for (uint32_t p = lane; p < P; p += kWave) { PartDesc d{}; d.frame = frame; pf[p] = d; }
-        if (lane == 0) list[1u + atomicAdd(&list[0], 1u)] = frame | (dense ? 0x80000000u : 0u);
+        for (uint32_t p = lane; p < P; p += kWave) {
+            PartDesc d{};
+            d.frame = frame;
+            if (one_unit && p == 0u) d.b1 = g.n_blocks;
+            pf[p] = d;
+        }
+        if (!one_unit && lane == 0) list[1u + atomicAdd(&list[0], 1u)] = frame | (dense ? 0x80000000u : 0u);
 #ifdef TRPX_PART_STATS
         if (lane == 0) atomicAdd(status + 2, 1u);
 #endif
@@ -612,7 +706,8 @@ hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t s
     hipLaunchKernelGGL(k_part_repair, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
                        static_cast<const PartState*>(states), static_cast<const PartWalk*>(walks), static_cast<const PartCk*>(cks), fixes);
     hipLaunchKernelGGL(k_part_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartState*>(states),
-                       static_cast<const PartWalk*>(walks), static_cast<const PartFix*>(fixes), a.geom, P, a.parts, a.defer, a.status);
+                       static_cast<const PartWalk*>(walks), static_cast<const PartFix*>(fixes), a.geom, P, a.frame_offsets, (uint64_t)a.terse_bytes,
+                       a.parts, a.defer, a.status);
     return hipGetLastError();
 }
 
