@@ -15,7 +15,7 @@ stats = {r["Name"]: float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(os.
 def kern(sub, label):
     f = next(v for (d, k, c), v in rows.items() if d == "enc_fetch" and sub in k and c == "FETCH_SIZE")
     w = next(v for (d, k, c), v in rows.items() if d == "enc_write" and sub in k and c == "WRITE_SIZE")
-    avg = next(v for k, v in stats.items() if sub.split("<")[0] in k and ("unsigned short" in k or "<" not in sub))
+    avg = next(v for k, v in stats.items() if sub in k)
     return {"fetch_bytes": int(2 * f * 1024), "write_bytes": int(w * 1024), "traffic_bytes": int(2 * f * 1024 + w * 1024), "rocprof_avg_ms": round(avg, 5)}
 cal = {k: v for k, v in rows.items() if k[0].startswith("cal_")}
 out = {
@@ -24,7 +24,7 @@ out = {
     "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE counts 64 B per 128-B request on gfx950 = half the bytes; calibrated in the same run with tools/membench, rows cal_fetch / cal_write of " + tag + "_pmc_traffic.txt)",
     "workload": "2000-frame 512x512 uint16 synth-v1 stack, per launch",
     "k_encode_fused<uint16_t>": kern("k_encode_fused<unsigned short>", "enc"),
-    "k_decode_frames<uint16_t>": kern("k_decode_frames<unsigned short>", "dec"),
+    "k_decode_frames<uint16_t>": kern("k_decode_frames<unsigned short", "dec"),
 }
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
