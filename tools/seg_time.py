@@ -23,7 +23,9 @@ def flip(frames):   # block width alternates 2 / 3 / 5 every block
     px[:, ::12] = hi[::12]
     return px.to(torch.int16).view(torch.uint16)
 
-sets = [("synth-v1 u16", lambda: codec.synth(np.uint16, 0, 2000, n), np.uint16),
+from trpx_amd import workloads
+sets = [("poisson3 u16", lambda: workloads.poisson_u16(3.0, 0, 2000, n, device=dev), np.uint16),
+        ("synth-v1 u16", lambda: codec.synth(np.uint16, 0, 2000, n), np.uint16),
         ("noisy u16", lambda: noisy("u16", 2000, False), np.uint16),
         ("noisy i16 (const width)", lambda: noisy("i16", 2000, True), np.int16),
         ("flip-every-block u16", lambda: flip(1000), np.uint16),

@@ -455,7 +455,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                 // changes inside the super-step just walked (9 or 12 widths per lane, outside the step loop).  (Probing the
                 // first 256 blocks instead -- a second bound in the fast loop -- hands a header-dense frame over after 0.06
                 // instead of 0.13 ms but cost every other stack 6-60 %: the loop bound became loop-variant.)
-                if (defer && !bad && (s == 0u || s == 3u || s == 11u) && end_nom == step_begin(s + 1u) && end_nom < n_blocks) {
+                if (defer && !bad && (s <= 1u || s == 3u || s == 11u) && end_nom == step_begin(s + 1u) && end_nom < n_blocks) {   // (1: a frame near the line that was early at 0 -- 37 % of a Poisson(3) stack -- sees the whole stack's count now, not three super-steps later)
                     const uint32_t per = (end_nom - beg_b) / kWave;                   // widths per lane (whole groups)
                     uint32_t changes = 0;
 #pragma unroll
@@ -482,14 +482,32 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                                                __HIP_MEMORY_SCOPE_AGENT);
                     uint64_t d_chg = chg, d_blk = blk;
                     if (chg * 100u > 14u * blk && chg * 100u < 30u * blk) {
-                        const uint64_t v = __hip_atomic_load(slots + lane * kDeferSlotWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        uint32_t c = (uint32_t)(v >> 32), n = (uint32_t)v;       // (2000 frames x 768 blocks: the sums fit 32 bits per slot and in all)
-                        c = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(c), 63);
-                        n = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n), 63);
+                        // (the stack's frames reach this point within microseconds of each other: a frame that is early waits -- a
+                        // few polls, bounded -- until 64 of them have reported, or it would decide on its own count after all and
+                        // be handed over three super-steps later)
+                        const uint32_t enough = (gridDim.x < 64u ? gridDim.x : 64u) * blk;
+                        uint32_t c = 0, n = 0;
+                        for (int poll = 0; poll < 24; ++poll) {
+                            const uint64_t v = __hip_atomic_load(slots + lane * kDeferSlotWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            c = (uint32_t)(v >> 32); n = (uint32_t)v;            // (2000 frames x 768 blocks: the sums fit 32 bits per slot and in all)
+                            c = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(c), 63);
+                            n = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n), 63);
+                            if (s != 0u || n >= enough) break;
+                            __builtin_amdgcn_s_sleep(16);
+                        }
                         if (s == 0u) { d_chg += c; d_blk += n; }                 // (own counts may or may not have arrived: once more or less)
                         else if (n) { d_chg = c; d_blk = n; }
                     }
-                    if (d_chg * (uint64_t)TRPX_DEFER_DEN > (uint64_t)TRPX_DEFER_NUM * d_blk && lane == 0) s_err = chg * 3u > blk ? 3u : 2u;   // (3: a change every third block and more -- listed without a search for runs)
+                    // (3: listed WITHOUT a search for runs -- a frame past this line has runs of four or five blocks, nothing the run
+                    // guess of decode_seg.hip could start in: the search cost every Poisson(3) frame 44 of 350 us)
+                    if (d_chg * (uint64_t)TRPX_DEFER_DEN > (uint64_t)TRPX_DEFER_NUM * d_blk && lane == 0) s_err = 3u;
+#ifdef TRPX_DEFER_STATS
+                    if (lane == 0) {       // diagnostic build: status[2..4] = frames handed over after super-step 0 / 3 / 11, [5] = decisions by the stack's count, [6] = sum of own densities (per mille) at step 0
+                        if (d_chg * (uint64_t)TRPX_DEFER_DEN > (uint64_t)TRPX_DEFER_NUM * d_blk) atomicAdd(status + (s == 0u ? 2 : s == 3u ? 3 : 4), 1u);
+                        if (d_blk != blk) atomicAdd(status + 5, 1u);
+                        if (s == 0u) atomicAdd(status + 6, chg * 1000u / blk);
+                    }
+#endif
                 }
             }
         } else if (s >= 1) {
