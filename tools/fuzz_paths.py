@@ -14,17 +14,30 @@ t0 = time.time()
 for c in range(cases):
     dt = np.dtype(DT[rng.randint(6)])
     top = 8 * dt.itemsize - (2 if dt.kind == "i" else (1 if dt.itemsize == 4 else 0))      # inside the reference's validity domain (D3)
-    n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3), 12 * 34000 + 8 * rng.randint(0, 3)]))
+    n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3), 12 * 34000 + 8 * rng.randint(0, 3),
+                        513 * 511, 12 * 70000 + rng.randint(0, 12), 1030 * 1065]))            # (> 32768 blocks: cut into parts, decode_part.hip)
     n = max(1, n - rng.randint(0, 4) * rng.randint(0, 2))                                     # (half of the cases: no multiple of 4)
-    frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else int(rng.choice([1, 3, 130]))
+    frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else (int(rng.choice([1, 3, 130])) if n <= 12 * 34000 + 16 else int(rng.choice([1, 2, 9])))
     nblk = (n + 11) // 12
-    kind = rng.randint(5)
+    kind = rng.randint(8)
     if kind == 0:   hi = np.full((frames, nblk), rng.randint(0, top + 1))                    # one width
     elif kind == 1: hi = rng.randint(0, top + 1, size=(frames, nblk))                        # every block its own width
     elif kind == 2: hi = np.where(rng.rand(frames, nblk) < 0.02, rng.randint(0, top + 1, size=(frames, nblk)), 3 if top >= 3 else 1)   # runs + outliers
     elif kind == 3: hi = np.where(rng.rand(frames, nblk) < 0.5, 2, 3 if top >= 3 else 1)    # flips every other block
-    else:           hi = np.repeat(rng.randint(0, top + 1, size=(frames, (nblk + 299) // 300)), 300, axis=1)[:, :nblk]   # long runs of changing widths
+    elif kind == 4: hi = np.repeat(rng.randint(0, top + 1, size=(frames, (nblk + 299) // 300)), 300, axis=1)[:, :nblk]   # long runs of changing widths
+    elif kind == 5:                                                                            # every frame its own rate of width changes (the hand-over's stack statistics)
+        rate = rng.choice([0.01, 0.1, 0.18, 0.25, 0.4], size=(frames, 1))
+        hi = np.where(rng.rand(frames, nblk) < rate, 2, 3 if top >= 3 else 1)
+    else:           hi = np.full((frames, nblk), min(top, 3))                                   # (6, 7: values set below)
     mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+    if kind == 6:                                                                              # a pedestal: constant top bits in every field
+        base = int(rng.choice([96, 100, 1000, 4000, 30000])) if dt.itemsize > 1 else int(rng.choice([16, 40, 96]))
+        base = min(base, (1 << top) - 8)
+        mag = base + (rng.rand(frames, n) * rng.choice([2, 7, 8])).astype(np.int64)
+        if rng.rand() < 0.5: mag = np.where(rng.rand(frames, n) < 1.0 / 4096, (rng.rand(frames, n) * (1 << top)).astype(np.int64), mag)
+    if kind == 7:                                                                              # Poisson counts + rare peaks: header-dense
+        mag = rng.poisson(rng.choice([0.3, 1.5, 3.0, 10.0]), size=(frames, n)).astype(np.int64)
+        mag = np.minimum(np.where(rng.rand(frames, n) < 1.0 / 4096, (rng.rand(frames, n) * (1 << min(top, 12))).astype(np.int64), mag), (1 << top) - 1)
     if rng.rand() < 0.3: mag[:, : n // 2] = 0                                                 # empty half frames
     if dt.kind == "i": mag = mag * rng.choice([-1, 1], size=mag.shape)
     px = mag.astype(dt)
