@@ -3,6 +3,8 @@
 tag=$1; lib=$2
 export TMPDIR=/tmp
 [ -n "$lib" ] && export TRPX_LIB=$lib
+rm -rf gpurun_out/${tag}_p[0-9]*    # one run per directory (the summary below insists on it)
+mkdir -p gpurun_out
 i=0
 for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_BUSY_CYCLES" \
            "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
@@ -16,6 +18,7 @@ import csv,glob,collections
 for i in (1,2,3,4):
     fs=glob.glob(f"gpurun_out/${tag}_p{i}/*/*counter_collection.csv")
     if not fs: print("pass", i, "failed"); continue
+    assert len(fs) == 1, f"gpurun_out/${tag}_p{i} holds {len(fs)} runs: clear it and run again"
     f=fs[0]
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
