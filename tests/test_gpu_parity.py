@@ -1384,3 +1384,131 @@ def test_large_frames_with_a_pedestal(gpu, oracle, dtype, lo, hi):
     back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
     torch.cuda.synchronize()
     assert int(st[0].item()) == 0 and torch.equal(back, px)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.int32])
+def test_large_frames_hostile_streams(gpu, oracle, dtype):
+    """Frames of more than 32 K blocks are cut at positions whose chain state is GUESSED and walked from there by walks that
+    tolerate anything (decode_part.hip) -- so what a damaged frame does to that route is tested on its own: one frame of a
+    stack of six is overwritten (ones, zeroes, noise, a burst, its first / last byte, single bits, offsets that run
+    backwards), everything else stays as the encoder wrote it.  The call must come back with status 0 or TRPX_ERR_CORRUPT
+    -- CORRUPT whenever the damage is gross --, the frames that were not touched must decode exactly whenever it says 0
+    (frames are independent: Terse.hpp:502-505), and the workspace must serve the next call (the hand-over list, the part
+    tables and the stack statistics live in it)."""
+    import torch
+    from trpx_amd import codec, _lib
+    n, frames, victim = 12 * 70000 + 5, 6, 2
+    px = codec.synth(dtype, 0, frames, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    good = enc.stack().clone()
+    offs = enc.frame_offsets.clone()
+    o = offs.cpu().numpy()
+    lo, hi = int(o[victim]), int(o[victim + 1])
+    want, _ = oracle.encode(px[victim].cpu().numpy())
+    assert good[lo:hi].cpu().numpy().tobytes() == want.tobytes()
+    ws = codec.Workspace(gpu)
+    view = torch.int32 if np.dtype(dtype).itemsize == 4 else torch.int16
+    others = [f for f in range(frames) if f != victim]
+
+    def run(stream, offsets=offs):
+        back, st = codec.decode(stream, offsets, n, frames, dtype, workspace=ws)
+        torch.cuda.synchronize()
+        return back, int(st[0].item())
+
+    def clean_call_still_works(after):
+        back, s = run(good)
+        assert s == 0 and torch.equal(back.view(view), px.view(view)), f"the workspace does not serve a clean call after: {after}"
+
+    clean_call_still_works("nothing")
+    g = torch.Generator().manual_seed(20260104)
+    gross = {"ones": lambda b: b[lo:hi].fill_(0xFF), "zeroes": lambda b: b[lo:hi].zero_(),
+             "noise": lambda b: b[lo:hi].copy_(torch.randint(0, 256, (hi - lo,), generator=g, dtype=torch.uint8).to(gpu)),
+             "burst": lambda b: b[(lo + hi) // 2: (lo + hi) // 2 + 4096].copy_(torch.randint(0, 256, (4096,), generator=g, dtype=torch.uint8).to(gpu))}
+    for what, spoil in gross.items():
+        bad = good.clone()
+        spoil(bad)
+        assert torch.equal(bad[:lo], good[:lo]) and torch.equal(bad[hi:], good[hi:])          # (only the victim's bytes)
+        back, s = run(bad)
+        assert s == _lib.ERR_CORRUPT, (what, s)
+        clean_call_still_works(what)
+    # small damage: a flip in payload bits still parses (status 0, the victim's pixels differ); one in a header or a width does not
+    positions = [lo, hi - 1] + [int(p) for p in torch.randint(lo, hi, (24,), generator=g)]
+    seen = {0: 0, _lib.ERR_CORRUPT: 0}
+    for k, p in enumerate(positions):
+        bad = good.clone()
+        bad[p] ^= 1 << (k % 8)
+        back, s = run(bad)
+        assert s in (0, _lib.ERR_CORRUPT), (p - lo, s)
+        seen[s] += 1
+        if s == 0:
+            for f in others:
+                assert torch.equal(back[f].view(view), px[f].view(view)), f"a flip in frame {victim} (byte {p - lo}) changed frame {f}"
+    assert seen[_lib.ERR_CORRUPT] > 0 and seen[0] > 0, seen        # (both kinds occurred: the check on the other frames above has run)
+    clean_call_still_works("single flips")
+    # offsets that run backwards / past the stream: refused, not followed
+    for what, k, v in (("backwards", victim + 1, lo - 5), ("past the end", frames, int(good.numel()) + 4096)):
+        ob = offs.clone()
+        ob[k] = v
+        back, s = run(good, ob)
+        assert s == _lib.ERR_CORRUPT, (what, s)
+        clean_call_still_works(what)
+
+
+@pytest.mark.parametrize("shape,frames,victim", [((512, 512), 70, 10), ((1030, 1065), 5, 2)])
+def test_header_dense_hostile_streams(gpu, oracle, shape, frames, victim):
+    """The same for the routes header-dense frames take -- Poisson(3) counts, a width change on one block in four: stacks of
+    512 x 512 frames are handed over by the per-frame decoder to the position-parallel walk with one wavefront per frame
+    (70 frames: the hand-over is decided by the stack's statistics), frames of 1030 x 1065 fall through the part cuts to the
+    walk with several wavefronts per frame (decode_seg.hip).  Both count their blocks from states that are guesses until the
+    links close, in passes that do not check widths against the pixel type: a damaged frame must end in TRPX_ERR_CORRUPT or,
+    where only payload bits changed, in status 0 with every other frame exact."""
+    import torch
+    from trpx_amd import codec, _lib, workloads
+    n = shape[0] * shape[1]
+    px = workloads.poisson_u16(3.0, 0, frames, n, device=gpu)
+    enc = codec.encode(px)
+    torch.cuda.synchronize()
+    enc.check()
+    good = enc.stack().clone()
+    offs = enc.frame_offsets.clone()
+    o = offs.cpu().numpy()
+    lo, hi = int(o[victim]), int(o[victim + 1])
+    want, _ = oracle.encode(px[victim].cpu().numpy())
+    assert good[lo:hi].cpu().numpy().tobytes() == want.tobytes()
+    ws = codec.Workspace(gpu)
+    others = [f for f in range(frames) if f != victim]
+
+    def run(stream):
+        back, st = codec.decode(stream, offs, n, frames, np.uint16, workspace=ws)
+        torch.cuda.synchronize()
+        return back, int(st[0].item())
+
+    def clean_call_still_works(after):
+        back, s = run(good)
+        assert s == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16)), f"the workspace does not serve a clean call after: {after}"
+
+    clean_call_still_works("nothing")
+    g = torch.Generator().manual_seed(20260105)
+    gross = {"ones": lambda b: b[lo:hi].fill_(0xFF), "zeroes": lambda b: b[lo:hi].zero_(),
+             "noise": lambda b: b[lo:hi].copy_(torch.randint(0, 256, (hi - lo,), generator=g, dtype=torch.uint8).to(gpu)),
+             "burst": lambda b: b[(lo + hi) // 2: (lo + hi) // 2 + 2048].copy_(torch.randint(0, 256, (2048,), generator=g, dtype=torch.uint8).to(gpu))}
+    for what, spoil in gross.items():
+        bad = good.clone()
+        spoil(bad)
+        back, s = run(bad)
+        assert s == _lib.ERR_CORRUPT, (what, s)
+        clean_call_still_works(what)
+    seen = {0: 0, _lib.ERR_CORRUPT: 0}
+    for k, p in enumerate([lo, hi - 1] + [int(q) for q in torch.randint(lo, hi, (22,), generator=g)]):
+        bad = good.clone()
+        bad[p] ^= 1 << (k % 8)
+        back, s = run(bad)
+        assert s in (0, _lib.ERR_CORRUPT), (p - lo, s)
+        seen[s] += 1
+        if s == 0:
+            for f in others:
+                assert torch.equal(back[f].view(torch.int16), px[f].view(torch.int16)), f"a flip in frame {victim} (byte {p - lo}) changed frame {f}"
+    assert seen[_lib.ERR_CORRUPT] > 0 and seen[0] > 0, seen
+    clean_call_still_works("single flips")
