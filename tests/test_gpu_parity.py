@@ -1512,3 +1512,71 @@ def test_header_dense_hostile_streams(gpu, oracle, shape, frames, victim):
                 assert torch.equal(back[f].view(torch.int16), px[f].view(torch.int16)), f"a flip in frame {victim} (byte {p - lo}) changed frame {f}"
     assert seen[_lib.ERR_CORRUPT] > 0 and seen[0] > 0, seen
     clean_call_still_works("single flips")
+
+
+def test_two_host_threads_share_the_library(gpu, oracle):
+    """Two host threads, each with its own stream, workspaces and data, encode and decode at the same time (ctypes releases
+    the GIL for the length of a call).  What they share is the library: the encoder's register of clean workspaces (one
+    mutex, encode_fused.hip -- a clearing launch skipped for the wrong workspace would mean a damaged stream or a look-back
+    timeout) and, per thread, the host wrappers' arena, error text and profiler (thread_local, api.hip).  Every stack must be
+    the one the thread's own data gives single-threaded -- byte for byte -- and decode back to it."""
+    import threading
+    import torch
+    from trpx_amd import codec
+    n, frames, rounds = 512 * 512, 64, 25
+    data, expect = [], []
+    for t in range(2):
+        px = codec.synth(np.uint16, 1000 * t, frames, n, device=gpu)
+        enc = codec.encode(px)
+        torch.cuda.synchronize()
+        enc.check()
+        want, _ = oracle.encode(px[0].cpu().numpy())
+        o = enc.frame_offsets.cpu().numpy()
+        assert enc.stack()[: int(o[1])].cpu().numpy().tobytes() == want.tobytes()
+        data.append(px)
+        expect.append((enc.stack().clone(), enc.frame_offsets.clone()))
+    assert not torch.equal(expect[0][0][:4096], expect[1][0][:4096])                     # (different data: cross-talk would show)
+    small = [np.random.RandomState(7 + t).poisson(2.0, (4, 256 * 256)).astype(np.uint16) for t in range(2)]
+    small_want = [np.concatenate([oracle.encode(f)[0] for f in s]) for s in small]
+    failures, gate = [], threading.Barrier(2)
+
+    def work(t):
+        try:
+            torch.cuda.set_device(gpu)
+            s = torch.cuda.Stream(device=gpu)
+            ws_e, ws_d = codec.Workspace(gpu), codec.Workspace(gpu)
+            px, (stack, offs) = data[t], expect[t]
+            cap = (frames * codec.worst_case_bytes(torch.uint16, n) + 15) // 16 * 16
+            out = torch.empty(cap, dtype=torch.uint8, device=gpu)
+            fo = torch.empty(frames + 1, dtype=torch.int64, device=gpu)
+            st_e = torch.empty(8, dtype=torch.int32, device=gpu)
+            st_d = torch.empty(8, dtype=torch.int32, device=gpu)
+            back = torch.empty_like(px)
+            gate.wait(timeout=60)
+            with torch.cuda.stream(s):
+                for r in range(rounds):
+                    e = codec.encode(px, out=out, workspace=ws_e, frame_offsets=fo, status=st_e)
+                    codec.decode(out, fo, n, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
+                    s.synchronize()
+                    if int(st_e[0].item()) != 0 or int(st_d[0].item()) != 0:
+                        failures.append((t, r, "status", int(st_e[0].item()), int(st_d[0].item())))
+                    elif not (torch.equal(fo, offs) and torch.equal(out[: stack.numel()], stack)):
+                        failures.append((t, r, "stream differs"))
+                    elif not torch.equal(back.view(torch.int16), px.view(torch.int16)):
+                        failures.append((t, r, "pixels differ"))
+            for r in range(3):                                                            # the host wrappers: per-thread arena and stream
+                got, ho, _ = _host_encode(small[t])
+                if got.tobytes() != small_want[t].tobytes():
+                    failures.append((t, r, "host stream differs"))
+                if not (_host_decode(got, ho, 256 * 256, 4, np.uint16) == small[t]).all():
+                    failures.append((t, r, "host pixels differ"))
+        except Exception as ex:                                                           # (an assert in a thread would be lost)
+            failures.append((t, "exception", repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=240)
+    assert not any(th.is_alive() for th in threads), "a thread did not come back"
+    assert not failures, failures[:5]
