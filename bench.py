@@ -418,11 +418,18 @@ def main():
             src = px.view(torch.uint8).reshape(-1)[:nbytes]
             dst = back.view(torch.uint8).reshape(-1)[:nbytes]
             sink = st_d if mode == 0 else dst
+            if mode == 3:                                     # from a 2-byte aligned address: the decoder's stores on frames that start inside a cache line
+                sink = back.view(torch.uint8).reshape(-1)[2: 2 + nbytes]
             s_ = torch.cuda.current_stream().cuda_stream
             ms = timed(lambda: _lib.check(L.trpx_bench_stream(mode, src.data_ptr(), sink.data_ptr(), nbytes, s_)), 10)
             return (2 if mode == 2 else 1) * nbytes / ms / 1e6
         measured = {"read_GBps": stream_GBps(0, pix_bytes), "write_GBps": stream_GBps(1, pix_bytes), "copy_GBps": stream_GBps(2, pix_bytes),
-                    "how": "trpx_bench_stream: grid-stride 16 B/lane non-temporal kernels over the stack's pixel bytes, HIP events, 10 launches"}
+                    "write_misaligned_GBps": stream_GBps(3, pix_bytes - 16),
+                    "how": "trpx_bench_stream: grid-stride 16 B/lane non-temporal kernels over the stack's pixel bytes, HIP events, 10 launches; "
+                           "write_misaligned: the same stores from a 2-byte aligned address"}
+        # (The write rates differ between the pool's boxes -- 4.8-6.7 / 3.5-5.0 TB/s over nine of them -- and the kernels that keep
+        # plain misaligned stores (`oddsize_u16` with the index) were fast only on the two fastest: DESIGN.md 8, tools/box_kind.py.
+        # The RATIO of the two rates hardly moves, 1.34-1.47, and tells nothing: it is not reported.)
         # (what the decoder left in `back` was overwritten: restore the headline result for the checks below)
         codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
         for r_, kind in ((roofs.get("encode"), "read"), (roofs.get("decode"), "write")):

@@ -201,6 +201,8 @@ int trpx_workspace_invalidate(const void* workspace, size_t workspace_bytes);
  * Measured memory ceilings for the benchmark's roofline block (SURVEY.md section 8 row d): one grid-stride streaming
  * kernel over `bytes` bytes, 16 bytes per lane, non-temporal.  mode 0 = read `src` (dst: a 4-byte device sink),
  * 1 = write `dst`, 2 = copy src -> dst.  Device pointers, 16-byte aligned; stream-ordered.  Bench utility, not codec.
+ * 3 = write `dst` from a 2-byte aligned address (the shape of the decoder's stores when a frame starts inside a cache line;
+ * the benchmark reports it next to mode 1 as the ceiling of the kernels that keep such stores).
  */
 int trpx_bench_stream(int mode, const void* src, void* dst, size_t bytes, void* stream);
 

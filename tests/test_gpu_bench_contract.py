@@ -80,6 +80,7 @@ def test_bench_reports_the_workloads_the_headline_hides():
             assert kk in leg, (k, kk)
         assert 0 < leg["decode_frac_of_hbm_peak"] < 1
     pm = b["peak_measured"]
+    assert 500 < pm["write_misaligned_GBps"] <= 1.05 * pm["write_GBps"], pm          # (the decoder's store shape on frames that start inside a line)
     assert min(pm["read_GBps"], pm["write_GBps"], pm["copy_GBps"]) > 1000, pm      # (200 frames fit the Infinity Cache: no upper bound here)
     rf = b["roofline"]
     assert rf["peak"] == 8000.0 and rf["peak_measured"] > 0 and abs(rf["frac_of_measured"] - rf["achieved"] / rf["peak_measured"]) < 1e-9
