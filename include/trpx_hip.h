@@ -190,8 +190,10 @@ int trpx_synth_fill(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, 
  * hence the rule: between two trpx_encode* calls a workspace belongs to the library.  Whoever writes into it, frees it or
  * hands its address to something else calls trpx_workspace_invalidate(workspace, workspace_bytes) first (NULL, 0: every
  * workspace the library remembers).  Entry points of this library that are given the memory for another purpose (trpx_decode
- * with the same workspace, another geometry, the two-pass pipeline) do so by themselves; a call that is captured into a HIP
- * graph always clears; and the encoder's first tile checks a tag it left in the workspace: a workspace that is not what the
+ * with the same workspace, another geometry, the two-pass pipeline, the *_host entry points' own buffers) do so by themselves;
+ * a call that is captured into a HIP graph always clears and neither reads nor writes what the library remembers (replays and
+ * eager calls may alternate on one workspace); the device that is current at the call is the one the kernels run on and has
+ * to own the workspace; and the encoder's first tile checks a tag it left in the workspace: a workspace that is not what the
  * library remembers makes the call report TRPX_ERR_TIMEOUT in the status block, which trpx_encode_checked and the host
  * wrappers answer with the two-pass pipeline (identical stream, none of these words).  Host-side, thread safe, no device call.
  */

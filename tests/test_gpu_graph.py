@@ -46,3 +46,44 @@ def test_encode_decode_capture_into_hip_graph(gpu):
     torch.cuda.synchronize()
     assert torch.equal(offs, fresh.frame_offsets) and torch.equal(out[: fresh.total_bytes()], fresh.stack())
     assert torch.equal(back.view(torch.int16), px.view(torch.int16))
+
+
+def test_eager_and_replayed_encodes_alternate_on_one_workspace(gpu, oracle):
+    """A captured call bakes its arguments in; the library's memory of clean workspaces is only updated by eager calls
+    (encode_fused.hip: launch_fused_t).  Capture -> eager -> replay -> eager -> replay -> eager on ONE workspace: every call
+    reports status 0 at its first attempt (no spurious TRPX_ERR_TIMEOUT from a tag the replay overwrote) and writes the
+    oracle's bytes."""
+    import torch
+    from trpx_amd import codec, _lib
+    n, frames = 512 * 512, 16
+    px = codec.synth(np.uint16, 3, frames, n, device=gpu)
+    want = oracle.encode_stack(px.cpu().numpy())[0].tobytes()
+    ws = codec.Workspace(gpu)
+    cap = (frames * codec.worst_case_bytes(np.uint16, n) + 15) // 16 * 16
+    out = torch.empty(cap, dtype=torch.uint8, device=gpu)
+    offs = torch.empty(frames + 1, dtype=torch.int64, device=gpu)
+    st = torch.empty(8, dtype=torch.int32, device=gpu)
+    ws.get(_lib.lib().trpx_encode_workspace_bytes(_lib.U16, n, frames, 12))
+
+    def eager():
+        out.zero_(); st.fill_(99)
+        codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st)
+        torch.cuda.synchronize()
+        assert int(st[0].item()) == 0, "eager call: device status %d at the first attempt" % int(st[0].item())
+        assert out[: int(offs[-1].item())].cpu().numpy().tobytes() == want
+
+    eager(); eager()                                                        # the workspace is remembered as clean
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st)
+
+    def replay():
+        out.zero_(); st.fill_(99)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(st[0].item()) == 0
+        assert out[: int(offs[-1].item())].cpu().numpy().tobytes() == want
+
+    eager(); replay(); eager(); eager(); replay(); replay(); eager()

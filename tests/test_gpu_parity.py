@@ -1362,6 +1362,63 @@ def test_encoder_workspace_between_calls(gpu, oracle):
     assert enc() == 0 and enc() == 0
 
 
+def test_default_workspace_is_not_remembered(gpu, oracle):
+    """codec.encode() without workspace= allocates its scratch itself and lets it die with the Encoded object: the library
+    must not remember that memory as a clean workspace (torch's allocator hands the block to the next tensor).  Encode, drop,
+    scribble over what comes back from the allocator -- all but the last words, where the tag sits --, encode the same
+    geometry again: status 0 at the first attempt, the oracle's bytes."""
+    import torch, gc
+    from trpx_amd import codec
+    n, frames = 512 * 512, 24
+    px = codec.synth(np.uint16, 11, frames, n, device=gpu)
+    want = oracle.encode_stack(px.cpu().numpy())[0].tobytes()
+    for _ in range(3):
+        e = codec.encode(px)
+        torch.cuda.synchronize()
+        assert int(e.status[0].item()) == 0 and e.stack().cpu().numpy().tobytes() == want
+        ws_bytes = e._retry[1].numel()
+        del e
+        gc.collect()
+        junk = torch.empty(ws_bytes - 4096, dtype=torch.uint8, device=gpu)  # (same size class: the caching allocator's block)
+        junk.fill_(0x5A)
+        torch.cuda.synchronize()
+        del junk
+
+
+def test_host_entry_points_share_the_arena_workspace(gpu, oracle):
+    """trpx_encode_host registers its thread's workspace slot as clean; trpx_group_states_host / trpx_frame_offsets_host write an
+    index / a walk's scratch into the same slot (api.hip: Arena).  Terse compress -> write() with the frame index -> compress
+    the next stack: the second encode must not trust a scribbled workspace (status 0, oracle bytes, no 0.25 s timeout)."""
+    import ctypes, time
+    from trpx_amd import _lib
+    L = _lib.lib()
+    n, frames = 512 * 512, 6
+    a = oracle.synth(np.uint16, 40, frames, n)
+    want, sizes, _ = oracle.encode_stack(a)
+    cap = frames * L.trpx_worst_case_bytes(_lib.U16, n, 12)
+    out = np.empty(cap, dtype=np.uint8)
+    total = ctypes.c_size_t(0)
+    offs = np.zeros(frames + 1, dtype=np.uint64)
+    pb = ctypes.c_uint32(0)
+
+    def enc():
+        t0 = time.time()
+        _lib.check(L.trpx_encode_host(_lib.U16, a.ctypes.data, n, frames, 12, out.ctypes.data, cap, ctypes.byref(total),
+                                      offs.ctypes.data, ctypes.byref(pb), 0))
+        assert time.time() - t0 < 0.2, "a look-back wait ran into its timeout"
+        assert out[: total.value].tobytes() == want.tobytes()
+
+    enc(); enc()
+    ng = L.trpx_group_count(n, 12)
+    states = np.zeros(frames * ng, dtype=np.uint64)
+    _lib.check(L.trpx_group_states_host(out.ctypes.data, total.value, offs.ctypes.data, n, frames, 12, 16, states.ctypes.data, 0))
+    enc()
+    got = np.zeros(frames + 1, dtype=np.uint64)
+    _lib.check(L.trpx_frame_offsets_host(out.ctypes.data, total.value, n, frames, 12, 16, got.ctypes.data, 0))
+    assert (got == offs).all()
+    enc(); enc()
+
+
 @pytest.mark.parametrize("dtype,lo,hi", [(np.uint16, 100, 108), (np.int32, 1000, 1024), (np.uint8, 192, 200), (np.int16, -300, -290)])
 def test_large_frames_with_a_pedestal(gpu, oracle, dtype, lo, hi):
     """Raw detector counts sit on a pedestal: every pixel in [lo, hi).  Their constant payload bits pass the run test of the

@@ -130,7 +130,9 @@ def encode(pixels: torch.Tensor, out: torch.Tensor | None = None, workspace: Wor
     if status is None:
         status = torch.empty(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
     ws_bytes = lib().trpx_encode_workspace_bytes(code, n_values, n_frames, block)
-    ws = (workspace or Workspace(dev)).get(ws_bytes)
+    # (no Workspace given: a plain tensor that nobody owns beyond Encoded._retry -- a throw-away Workspace object would
+    # invalidate in its destructor BEFORE the call below registers the memory as clean)
+    ws = workspace.get(ws_bytes) if workspace is not None else torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
     if index is True:     # also keep the decode index (not part of the bitstream)
         index = torch.empty(index_bytes(px.dtype, n_values, n_frames, block), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -138,6 +140,11 @@ def encode(pixels: torch.Tensor, out: torch.Tensor | None = None, workspace: Wor
                                         frame_offsets.data_ptr(), status.data_ptr(),
                                         index.data_ptr() if index is not None else None, ws.data_ptr(), ws.numel(),
                                         _stream_ptr(px)))
+        if workspace is None:
+            # The buffer dies with the Encoded object and goes back to torch's allocator, which may hand its address to
+            # anything: the library must not remember it as a clean workspace (include/trpx_hip.h, "Workspaces between
+            # calls"; the registry is host-side, so forgetting right behind the launch is safe).
+            check(lib().trpx_workspace_invalidate(ws.data_ptr(), ws.numel()))
     return Encoded(out, frame_offsets, status, n_values, n_frames, px.dtype, index if index is not None else None, (px, ws, block))
 
 

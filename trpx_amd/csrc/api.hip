@@ -525,9 +525,12 @@ struct Arena {
         if (dev != device) { release(); device = dev; }
         return hipSuccess;
     }
-    hipError_t get(int slot, size_t n, void** out) {
+    // (the workspace slot is the one piece of memory trpx_encode registers as a clean descriptor block: every OTHER user of
+    // it -- an index, a walk's scratch -- makes the library forget that first; `encoder` = trpx_encode_host itself)
+    hipError_t get(int slot, size_t n, void** out, bool encoder = false) {
         hipError_t e = on_device();
         if (e != hipSuccess) return e;
+        if (slot == kWorkspace && !encoder && p[slot]) trpx::fused_ws_forget(p[slot], cap[slot]);
         if (cap[slot] < n) {
             if (p[slot] && slot == kWorkspace) trpx::fused_ws_forget(p[slot], cap[slot]);
             if (p[slot]) (void)hipFree(p[slot]);
@@ -594,7 +597,7 @@ int trpx_encode_host(int dtype, const void* pixels, size_t n_values, size_t n_fr
     HIP_TRY(A.get(Arena::kStream, cap, &d_out.p));
     HIP_TRY(A.get(Arena::kOffsets, 8 * (n_frames + 1), &d_off.p));
     HIP_TRY(A.get(Arena::kStatus, 4 * TRPX_STATUS_WORDS, &d_st.p));
-    HIP_TRY(A.get(Arena::kWorkspace, ws_bytes, &d_ws.p));
+    HIP_TRY(A.get(Arena::kWorkspace, ws_bytes, &d_ws.p, true));
     HIP_TRY(copy_sync(hs, d_px.p, pixels, in_bytes, hipMemcpyHostToDevice));
     int rc = trpx_encode(dtype, d_px.p, n_values, n_frames, block, static_cast<uint8_t*>(d_out.p), cap,
                          static_cast<uint64_t*>(d_off.p), static_cast<uint32_t*>(d_st.p), d_ws.p, ws_bytes, hs);

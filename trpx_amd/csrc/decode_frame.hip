@@ -194,6 +194,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     // (requested four widths per lane and load -- one unaligned dword: three registers in flight per 768 blocks, not twelve)
     constexpr int kIdxChunks = IDX ? kStepBlocks / kWave : 1;
     constexpr int kIdxQuads = IDX ? kStepBlocks / (4 * kWave) : 1;
+    static_assert(!IDX || kStepBlocks % (4 * kWave) == 0, "the width prefetch covers a super-step in whole quads of 64 lanes (TRPX_FRAME_GPW: a multiple of 4 per three extraction waves)");
     __shared__ __attribute__((aligned(4))) uint8_t s_wnext[IDX ? kStepBlocks : 4];
     [[maybe_unused]] auto idx_load = [&](uint32_t ss, uint32_t (&dst)[kIdxQuads]) {
         const uint8_t* __restrict__ wfl = idx_widths + frame * g.n_blocks + pb0;

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(kThreads) void k_stitch(uint64_t* __restrict__ tile
         if (m) atomicMax(&status[1], m);
     }
     for (uint64_t i = b; i < n_frame_words; i += (uint64_t)gridDim.x * kThreads) frame_words[i] = 0ull;
-    if (b == 0) ws_tag[0] = tag;
+    if (b == 0 && ws_tag) ws_tag[0] = tag;                                // (captured calls leave the tag alone: see launch_fused_t)
     if (b >= n_tiles) return;
     tile_desc[b] = 0ull;
     if (failed || b == 0) { xw[b] = 0ull; return; }
@@ -943,7 +943,11 @@ size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames) {
 // first tile compares the tag: a workspace that is not what the library remembers makes the call report TRPX_ERR_TIMEOUT -- the
 // status the checked entry points answer with the two-pass pipeline, which uses none of these words.
 namespace {
-struct CleanWs { int device; const void* ptr; uint64_t sig, tag; };
+struct CleanSig {                                                         // the geometry a clean workspace was laid out for, field by field
+    uint32_t elem, tiles_per_frame, n_frames, n_blocks;
+    bool operator==(const CleanSig& o) const { return elem == o.elem && tiles_per_frame == o.tiles_per_frame && n_frames == o.n_frames && n_blocks == o.n_blocks; }
+};
+struct CleanWs { int device; const void* ptr; CleanSig sig; uint64_t tag; };
 std::mutex g_clean_mu;
 std::vector<CleanWs> g_clean;                                             // a handful of entries: linear search
 uint64_t g_next_tag = 0x5452505800000001ull;
@@ -983,19 +987,25 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
 #else
     a.debug = 0u;
 #endif
-    // Is the workspace known to be clean (see above)?  Never while the stream is being captured.
+    // Is the workspace known to be clean (see above)?  A call that is being CAPTURED never relies on it (a replay does not pass
+    // through here): it always clears, and it leaves the registry and the TAG WORD alone -- its clearing launch stops in front
+    // of the tag and its k_stitch does not write one -- so that replays and eager calls can alternate on one workspace: every
+    // call, replayed or not, leaves the descriptor words clean, and the tag stays the last eager call's.  (A replay that wrote its
+    // baked-in tag made the next eager call find "not the workspace I remember": a spurious TRPX_ERR_TIMEOUT.)
+    // The current device is the one the kernels below run on, i.e. the one that has to own the workspace.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
     int device = -1;
     (void)hipGetDevice(&device);
-    const uint64_t sig = ((uint64_t)sizeof(T) << 56) ^ ((uint64_t)a.tiles_per_frame << 32) ^ (uint64_t)e.n_frames ^ ((uint64_t)e.geom.n_blocks << 8);
-    uint64_t expect = 0, tag;
-    {
+    const CleanSig sig{(uint32_t)sizeof(T), a.tiles_per_frame, e.n_frames, e.geom.n_blocks};
+    uint64_t expect = 0, tag = 0;
+    if (!capturing) {
         std::lock_guard<std::mutex> lk(g_clean_mu);
         tag = g_next_tag++;
         for (size_t i = 0; i < g_clean.size(); ++i)
             if (g_clean[i].device == device && g_clean[i].ptr == ws) {
-                if (g_clean[i].sig == sig && cap == hipStreamCaptureStatusNone) expect = g_clean[i].tag;
+                if (g_clean[i].sig == sig) expect = g_clean[i].tag;
                 g_clean[i] = g_clean.back(); g_clean.pop_back();            // (re-entered below if this call leaves it clean)
                 break;
             }
@@ -1006,7 +1016,7 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     prof.mark(st);
     if (expect == 0)   // unknown workspace: every polled / OR-ed word, the tag and the status block (a kernel, not a memset node: see k_zero_words)
         hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
-                           (uint64_t)(3 * tiles + 18 * e.n_frames + 1), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
+                           (uint64_t)(3 * tiles + 18 * e.n_frames + (capturing ? 0 : 1)), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
     prof.mark(st);
     hipLaunchKernelGGL((k_encode_fused<T>), dim3(a.tiles_per_frame, e.n_frames < kGridY ? e.n_frames : kGridY, (e.n_frames + kGridY - 1) / kGridY),
                        dim3(kThreads), 0, st,
@@ -1014,10 +1024,10 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     prof.mark(st);
     hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                        a.tile_desc, a.tail_desc, static_cast<const uint64_t*>(a.bnd_pos), (uint64_t)tiles, a.frame_acc, (uint64_t)(18 * (size_t)e.n_frames),
-                       a.ws_tag, tag, a.out32, (uint64_t)e.out_capacity, a.status);
+                       capturing ? static_cast<uint64_t*>(nullptr) : a.ws_tag, tag, a.out32, (uint64_t)e.out_capacity, a.status);
     prof.mark(st);
     const hipError_t err = hipGetLastError();
-    if (err == hipSuccess && cap == hipStreamCaptureStatusNone) {
+    if (err == hipSuccess && !capturing) {
         std::lock_guard<std::mutex> lk(g_clean_mu);
         if (g_clean.size() >= 64) g_clean.erase(g_clean.begin());
         g_clean.push_back(CleanWs{device, ws, sig, tag});
