@@ -32,7 +32,7 @@ extern "C" {
 /* 2: the opaque decode index / workspace layouts grew (hand-over list with its statistics, part table); trpx_bench_stream.
  * A caller compiled against one version must not run against a library of another: size its buffers with THIS library's
  * trpx_index_bytes / trpx_*_workspace_bytes and compare trpx_abi_version() with TRPX_ABI_VERSION first (the Terse classes do). */
-#define TRPX_ABI_VERSION 2
+#define TRPX_ABI_VERSION 3
 
 typedef enum trpx_status {
     TRPX_OK = 0,
@@ -75,6 +75,10 @@ size_t trpx_worst_case_bytes(int dtype, size_t n_values, unsigned block);
 /* Workspace sizes (bytes) for the device entry points below.  Pure arithmetic. */
 size_t trpx_encode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
 size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
+/* How many parts trpx_decode cuts a frame of this geometry into on the current route (1: frames are not cut; large frames --
+ * more than 32 K blocks -- are: Terse.hpp:360-372's serial chain is walked as many short chains, decode_part.hip).  For tests
+ * and diagnostics; pure arithmetic. */
+unsigned trpx_decode_parts_per_frame(int dtype, size_t n_values, size_t n_frames, unsigned block);
 
 /*
  * Encode n_frames frames of n_values pixels each (contiguous, frame-major, DEVICE memory) into
@@ -222,7 +226,7 @@ int trpx_set_encode_path(int path);
  * 3 = the per-frame decoder whenever its preconditions hold (= auto for trpx_decode; trpx_decode_indexed, which takes
  * it from 1024 frames on, then uses it for any number).  Every route yields the same pixels (Terse.hpp:352-389); the
  * setter exists for tests and A/B measurements.
- * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames.
+ * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames|parts.
  * These two variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
  * The tuned kernels issue 8- and 16-byte accesses at addresses that are only aligned to the pixel type (frames of any
  * pixel count): they rely on the HSA unaligned-access mode, which ROCm enables on gfx950.

@@ -1036,7 +1036,7 @@ def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):
 
 
 # ---- the decode route matrix: every route x every pixel type on the fuzz generator ---------------------
-_ROUTES = {"basic": 1, "tiles": 2, "frames": 3}
+_ROUTES = {"basic": 1, "tiles": 2, "frames": 3, "parts": 4}   # (4: large frames by round 4's parts route instead of the index route; = auto for small frames)
 
 
 def _fuzz_stack(rng, dt, kind, n, frames):
@@ -1276,6 +1276,16 @@ def test_large_frames_are_cut_into_parts(gpu, oracle, dtype, rows, width, frames
     torch.cuda.synchronize()
     assert int(st[0].item()) == 0
     assert torch.equal(back.view(torch.uint8), px.view(torch.uint8).reshape(frames, -1))
+    # round 4's parts route (two walks; its header-dense frames are listed for the position-parallel walk, whose launches for a
+    # list are one persistent kernel since round 5: k_seg_fallback) must give the same pixels
+    from trpx_amd import _lib
+    try:
+        assert _lib.lib().trpx_set_decode_path(4) == 0
+        back4, st4 = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().trpx_set_decode_path(0)
+    assert int(st4[0].item()) == 0 and torch.equal(back4.view(torch.uint8), px.view(torch.uint8).reshape(frames, -1))
     # a flipped bit in the middle of a large frame must not go unnoticed (every part checks the state it ends in)
     bad = enc.stack().clone()
     mid = int(o[1] + (o[2] - o[1]) // 2) if frames > 2 else int(o[0] + (o[1] - o[0]) // 2)
@@ -1302,7 +1312,7 @@ def test_large_frames_every_part_link_repaired(gpu, oracle, tmp_path):
 import sys
 sys.path.insert(0, {ROOT!r})
 import numpy as np, torch
-from trpx_amd import codec
+from trpx_amd import codec, _lib
 rng = np.random.RandomState(5)
 for dtype, n, frames in ((np.uint16, 1030 * 1065, 12), (np.int32, 2048 * 2048 + 5, 2)):
     a = rng.randint(0, 8, (frames, n)).astype(dtype)
@@ -1311,11 +1321,24 @@ for dtype, n, frames in ((np.uint16, 1030 * 1065, 12), (np.int32, 2048 * 2048 + 
         a[:, 1::384] = -9
     px = torch.from_numpy(a).cuda()
     enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+    # the index route (default): no cut finds a run, no part warms up in this build -- every link between two parts is open and
+    # repaired, and every repaired part's entries are spliced from the repair's and its own walk's (none is walked again)
+    P = _lib.lib().trpx_decode_parts_per_frame(codec.dtype_code(dtype), n, frames, 12)
     back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
     torch.cuda.synchronize()
     s = st.cpu().numpy()
     assert s[0] == 0 and torch.equal(back, px), s
-    assert s[2] == 0 and s[3] > 0 and s[5] == s[3] and s[6] == 0, s      # no fallback; plain guesses == repaired links; no failed repair
+    # (a part of ~1000 blocks on a chain that has not merged with the frame's by its end leaves the NEXT repair a false start:
+    # such a frame -- a few of them here, none with real cuts, which warm up -- is listed for the other route and still exact)
+    assert P > 3 and s[4] == 0 and s[5] + s[6] == frames * (P - 2) and s[5] > 9 * s[6] and s[2] <= frames, (P, s)
+    # round 4's parts route: plain guesses == repaired links; no fallback, no failed repair
+    assert _lib.lib().trpx_set_decode_path(4) == 0
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
+    torch.cuda.synchronize()
+    _lib.lib().trpx_set_decode_path(0)
+    s = st.cpu().numpy()
+    assert s[0] == 0 and torch.equal(back, px), s
+    assert s[2] == 0 and s[3] > 0 and s[5] == s[3] and s[6] == 0, s
 print("OK")
 """)
     r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))

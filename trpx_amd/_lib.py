@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("TRPX_LIB") or os.path.join(_HERE, "libtrpx_hip.so")  
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_CORRUPT, ERR_NO_DEVICE, ERR_TIMEOUT = range(8)
 U8, I8, U16, I16, U32, I32, F32, F64, U64, I64 = range(10)
 STATUS_WORDS = 8
-ABI_VERSION = 2          # TRPX_ABI_VERSION of include/trpx_hip.h (tests/test_abi.py compares them)
+ABI_VERSION = 3          # TRPX_ABI_VERSION of include/trpx_hip.h (tests/test_abi.py compares them)
 
 
 class TrpxError(RuntimeError):
@@ -41,6 +41,7 @@ SYMBOLS = {
     "trpx_worst_case_bytes": (_SZ, [_I, _SZ, _U]),
     "trpx_encode_workspace_bytes": (_SZ, [_I, _SZ, _SZ, _U]),
     "trpx_decode_workspace_bytes": (_SZ, [_I, _SZ, _SZ, _U]),
+    "trpx_decode_parts_per_frame": (_U, [_I, _SZ, _SZ, _U]),
     "trpx_encode": (_I, [_I, _P, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "trpx_decode": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _U, _P, _P, _P, _SZ, _P]),
     "trpx_index_bytes": (_SZ, [_I, _SZ, _SZ, _U]),

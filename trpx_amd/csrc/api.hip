@@ -79,12 +79,14 @@ int g_encode_path = [] {
     return e && strcmp(e, "twopass") == 0 ? 1 : 0;
 }();
 // Decode route: 0 = auto, 1 = basic (decode.hip), 2 = tiled (position-parallel walk + k_unpack_tiles), 3 = per-frame
-// decoder for any number of frames.  Initialised from $TRPX_DECODE_PATH ("basic" / "tiles" / "frames"), changed by
-// trpx_set_decode_path().  A forced route is still subject to its preconditions (alignment, block = 12, frame size).
+// decoder for any number of frames, 4 = large frames by round 4's parts route (two walks) instead of the index route.
+// Initialised from $TRPX_DECODE_PATH ("basic" / "tiles" / "frames" / "parts"), changed by trpx_set_decode_path().  A forced
+// route is still subject to its preconditions (alignment, block = 12, frame size).
 int g_decode_path = [] {
     const char* e = getenv("TRPX_DECODE_PATH");
     if (!e) return 0;
-    return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3 : 0;
+    return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3
+           : strcmp(e, "parts") == 0 ? 4 : 0;
 }();
 struct IdxLayout { size_t group_off, widths, seg, defer, total; };
 IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
@@ -106,9 +108,10 @@ DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     w.seg = trpx::align_up(w.widths + n_frames * (size_t)g.n_blocks, 256);
     w.defer = w.seg + trpx::seg_workspace_bytes(g, n_frames);
     w.parts = w.defer + trpx::defer_bytes(n_frames);                            // large frames on the per-frame route: the part table
-    const size_t P = trpx::parts_per_frame(g, n_frames);
+    // (two routes for large frames share these two areas: the index route -- many short parts -- and round 4's parts route)
+    const size_t P = std::max<size_t>(trpx::parts_per_frame(g, n_frames), trpx::chain_parts_per_frame(g, n_frames));
     w.part_ws = w.parts + (P > 1 ? trpx::align_up(sizeof(trpx::PartDesc) * n_frames * P, 256) : 0);
-    w.total = w.part_ws + trpx::part_workspace_bytes(g, n_frames);
+    w.total = w.part_ws + std::max(trpx::part_workspace_bytes(g, n_frames), trpx::chain_workspace_bytes(g, n_frames));
     return w;
 }
 
@@ -153,6 +156,13 @@ size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, 
     trpx::FrameGeom g;
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g)) return 0;
     return dec_ws(g, n_frames).total;
+}
+
+unsigned trpx_decode_parts_per_frame(int dtype, size_t n_values, size_t n_frames, unsigned block) {
+    trpx::FrameGeom g;
+    if (!trpx_dtype_size(dtype) || is64(dtype) || block != (unsigned)trpx::kBlock || !geom_of(n_values, block, &g)) return 1;
+    const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) < 0xF0000000ull;
+    return g_decode_path != 4 && bits32 ? trpx::chain_parts_per_frame(g, n_frames) : trpx::parts_per_frame(g, n_frames);
 }
 
 static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
@@ -301,7 +311,8 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
     // larger frames, or frames of more than 32 K blocks: cut into parts of the size of a 512 x 512 frame first (decode_part.hip);
     // a part's positions are relative to its own first bit, so the 2^26 limit applies to the part
-    a.parts_per_frame = trpx::parts_per_frame(g, n_frames);
+    a.chain = route != 4 && bits32;                                            // (frame-relative 32-bit positions)
+    a.parts_per_frame = a.chain ? trpx::chain_parts_per_frame(g, n_frames) : trpx::parts_per_frame(g, n_frames);
     const bool parts_ok = a.parts_per_frame > 1u && n_frames * (uint64_t)a.parts_per_frame < 0x7FFFFFFFull && a.defer;
     if (parts_ok) {
         a.parts = reinterpret_cast<trpx::PartDesc*>(ws + w.parts);
@@ -481,7 +492,7 @@ int trpx_set_encode_path(int path) {
 }
 
 int trpx_set_decode_path(int path) {
-    if (path < 0 || path > 3) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_decode_path: 0 = auto, 1 = basic, 2 = tiled, 3 = per-frame");
+    if (path < 0 || path > 4) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_decode_path: 0 = auto, 1 = basic, 2 = tiled, 3 = per-frame, 4 = parts route for large frames");
     g_decode_path = path;
     return TRPX_OK;
 }

@@ -119,7 +119,21 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
     // (`limit` = the frame's bits behind the unit's first), the output pointer.
     uint64_t frame = item;
     uint32_t pb0 = 0, pb1 = g.n_blocks, ppos0 = 0, pw0 = 0, ppos1 = 0, pw1 = 0;
-    if constexpr (PARTS) {                                                // (without a part table all of this folds to constants)
+    if constexpr (PARTS && MODE == 1) {
+        // UNITS of a frame whose decode index is known: blocks [u * unit_blocks, (u + 1) * unit_blocks) -- a multiple of 256, so the
+        // index holds the chain state in front of every unit (the group's bit offset, the width of the block before it)
+        const uint32_t unit_blocks = (uint32_t)(uintptr_t)parts;          // (the part-table argument carries the unit size here)
+        const uint32_t upf = (g.n_blocks + unit_blocks - 1u) / unit_blocks;
+        frame = item / upf;
+        pb0 = (uint32_t)(item % upf) * unit_blocks;
+        pb1 = pb0 + unit_blocks < g.n_blocks ? pb0 + unit_blocks : g.n_blocks;
+        ppos0 = (uint32_t)idx_group_off[frame * g.n_tiles + pb0 / (uint32_t)kTileBlocks];
+        pw0 = pb0 ? (uint32_t)idx_widths[frame * g.n_blocks + pb0 - 1u] : 0u;
+        if (pb1 < g.n_blocks) {
+            ppos1 = (uint32_t)idx_group_off[frame * g.n_tiles + pb1 / (uint32_t)kTileBlocks];
+            pw1 = (uint32_t)idx_widths[frame * g.n_blocks + pb1 - 1u];
+        }
+    } else if constexpr (PARTS) {                                         // (without a part table all of this folds to constants)
         const PartDesc d = parts[item];                                   // (uniform address: scalar loads)
         frame = d.frame; pb0 = d.b0; pb1 = d.b1; ppos0 = d.pos0; pw0 = d.w0; ppos1 = d.pos1; pw1 = d.w1;
         if (pb1 <= pb0) return;                                           // the frame took another route
@@ -741,6 +755,39 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
     decode_frame_body<T, 1>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
 }
 
+// Large frames whose index is known, in units of `unit_blocks` blocks (a multiple of 256 and of a super-step): the same body, one
+// workgroup per unit -- for 8- and 16-bit pixels faster than the tiled kernel (128 x 2048^2 u16: k_unpack_tiles 370 us).
+template <typename T>
+__global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_units_indexed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                               const uint64_t* __restrict__ frame_offsets, FrameGeom g,
+                                                               const uint8_t* __restrict__ widths, const uint64_t* __restrict__ group_off,
+                                                               uint32_t unit_blocks, T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+    if (status[0] != 0u) return;
+    decode_frame_body<T, 1, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, blockIdx.x, widths, group_off,
+                                  reinterpret_cast<const PartDesc*>((uintptr_t)unit_blocks));
+}
+template <typename T>
+static hipError_t launch_decode_units_indexed_t(const DecodeArgs& a, hipStream_t st) {
+    constexpr uint32_t unit_blocks = 8u * FrameCfg<T>::kStepBlocks;          // 6144 blocks: eight super-steps, 24 groups of 256
+    static_assert(unit_blocks % kTileBlocks == 0, "units start on index groups");
+    const uint32_t upf = (a.geom.n_blocks + unit_blocks - 1u) / unit_blocks;
+    hipLaunchKernelGGL((k_decode_units_indexed<T>), dim3(a.n_frames * upf), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), unit_blocks,
+                       static_cast<T*>(a.pixels_out), a.status);
+    return hipGetLastError();
+}
+hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st) {
+    switch (dtype) {
+    case 0: return launch_decode_units_indexed_t<uint8_t>(a, st);
+    case 1: return launch_decode_units_indexed_t<int8_t>(a, st);
+    case 2: return launch_decode_units_indexed_t<uint16_t>(a, st);
+    case 3: return launch_decode_units_indexed_t<int16_t>(a, st);
+    case 4: return launch_decode_units_indexed_t<uint32_t>(a, st);
+    case 5: return launch_decode_units_indexed_t<int32_t>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 // The index of every frame of a stack of small frames (MODE 2 above); T stands for the width limit only.
 template <typename T>
 __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_index_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
@@ -797,7 +844,29 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    if (a.parts && a.parts_per_frame > 1u) {
+    if (a.chain && a.parts && a.parts_per_frame > 1u) {
+        // Large frames by the index route (decode_part.hip): one walk of many short parts writes the decode index, the frames
+        // where that does not work out are listed and get theirs from the position-parallel walk, then every frame's tiles are
+        // extracted with the widths given.
+        if (!defer) return hipErrorInvalidValue;
+        constexpr int dt = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
+                           : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2) : (PixelTraits<T>::is_signed ? 5 : 4);
+        hipError_t e = launch_build_index_chain(a, (uint32_t)PixelTraits<T>::bits, st);
+        if (e != hipSuccess) return e;
+        prof.mark(st);
+        e = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
+        if (e != hipSuccess) return e;
+        // (the tiled kernel, or units of the per-frame decoder with the widths given: eight 4096^2 int32 frames 0.406 / 0.444 ms,
+        // 200 x (1030 x 1065) u16 0.246 / 0.268, 128 x 2048^2 u16 0.594 / 0.554 -- tools/r5_ab.sh xtiles / xunits)
+#ifdef TRPX_CHAIN_EXTRACT_TILES
+        const bool tiles = TRPX_CHAIN_EXTRACT_TILES != 0;
+#else
+        const bool tiles = sizeof(T) == 4 || a.geom.n_blocks < (1u << 18);
+#endif
+        e = tiles ? launch_unpack_tiles(dt, a, st) : launch_decode_units_indexed(dt, a, st);
+        prof.mark(st);
+        return e;
+    } else if (a.parts && a.parts_per_frame > 1u) {
         // Large frames: cut into parts first (decode_part.hip: a walk-only pass from guessed states inside runs of equal widths,
         // verified link by link); frames whose parts cannot be established -- no runs to start from: header-dense data -- are
         // listed in a.defer as whole frames and take the position-parallel walk + tiled extraction below.

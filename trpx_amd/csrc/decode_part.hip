@@ -50,6 +50,8 @@ constexpr uint32_t kPartSearch = TRPX_PART_SEARCH;   // passes of 2048 candidate
 constexpr uint32_t kPartCk = 256;              // checkpoints per part
 constexpr uint32_t kPartWeak = 0x80000000u;    // PartState::w: a plain guess (not expected to be a state of the chain)
 constexpr uint32_t kPartAmbig = 0x40000000u;   //   ... because runs were found, but not which of their passing positions is the header's
+constexpr uint32_t kPartRuns = 0x20000000u;    //   ... (index route) although runs of equal widths lie nearby: run-dominated data, where a false chain is slow to merge
+constexpr uint32_t kPartFlags = kPartWeak | kPartAmbig | kPartRuns;
 
 struct PartState { uint32_t pos, w; };
 struct PartCk { uint32_t pos, w, cnt; };
@@ -58,7 +60,8 @@ struct PartWalk {                              // what k_part_walk leaves per (f
     uint32_t cnt;                              // blocks started in [S_p, T_p)
     uint32_t flags;                            // 1: the chain left the frame / held an illegal width; 2: too dense for the serial walker
     uint32_t n_ck;                             // checkpoints left behind
-    uint32_t pad[3];
+    uint32_t s_pos, s_w;                       // (index route) the state the counting walk started in: the guess, or where the warm-up chain crossed the cut
+    uint32_t pad;
 };
 struct PartFix {                               // what k_part_repair leaves per (frame, part 1 <= p < P - 1)
     uint32_t state;                            // 0: link closed, nothing done; 1: merged into the part's walk; 2: walked to T_p on its own; 3: failed
@@ -108,11 +111,17 @@ struct PartWin {                               // the frame's stream behind an L
     uint32_t frame_sh;                         // bit of the frame's first bit inside that dword
     bool base16;
     int32_t c_lo, c_hi;                        // the window holds dwords [c_lo, c_hi) of the frame
+#ifdef TRPX_CHAIN_STAMPS
+    uint32_t n_fill = 0, t_fill = 0;           // diagnostic build: window fills and the 10 ns ticks they took
+#endif
 };
 
 // Window := the kPartChunkDw dwords from the (16-byte aligned) dword that holds frame bit `pos` on.
 __device__ __forceinline__ void part_fill(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t pos) {
     const uint32_t lane = (uint32_t)lane_id();
+#ifdef TRPX_CHAIN_STAMPS
+    const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t need_lo = (W.frame_sh + pos) >> 5;
     W.c_lo = (int32_t)(((W.frame_dw + need_lo) & ~3ull) - W.frame_dw);
     W.c_hi = W.c_lo + kPartChunkDw;
@@ -135,6 +144,10 @@ __device__ __forceinline__ void part_fill(PartWin& W, uint32_t* __restrict__ s_c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef TRPX_CHAIN_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    ++W.n_fill; W.t_fill += (uint32_t)(__builtin_amdgcn_s_memrealtime() - st_t0);
+#endif
 }
 
 // 32 stream bits from frame bit q on (inside the window)
@@ -198,8 +211,9 @@ __device__ __forceinline__ uint32_t part_header_phase(const uint32_t* __restrict
     return n_found == 1u ? found : ~0u;
 }
 
+// reach: the search (and the state it returns) stays inside [X, X + reach).
 __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t* __restrict__ s_pm, uint32_t X, uint32_t limit,
-                                                uint32_t max_w) {
+                                                uint32_t max_w, uint32_t reach = 0xFFFFFFFFu, uint32_t max_passes = kPartSearch) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t s_max = 1u + (uint32_t)kBlock * max_w;
     const PartState plain{X, kPartWeak};
@@ -208,8 +222,9 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
 #endif
     // the search range and its evidence lie inside one window: [X, X + 2048 kPartSearch + kPartEvid s_max) < 64 K bits
     static_assert(2048u * kPartSearch + kPartEvid * (1u + 12u * 32u) + 256u < 32u * (uint32_t)kPartChunkDw - 128u, "one window per guess");
-    uint32_t passes = kPartSearch;
+    uint32_t passes = max_passes < kPartSearch ? max_passes : kPartSearch;
     while (passes && (uint64_t)X + 2048ull * passes + (uint64_t)kPartEvid * s_max + 128u > (uint64_t)limit) --passes;   // too close to the frame's end
+    while (passes && 2048ull * passes + (uint64_t)kPartSkip * s_max > (uint64_t)reach) --passes;
     if (passes == 0u) return plain;
     part_fill(W, s_chunk, X);
 #ifdef TRPX_PART_NOGUESS
@@ -229,7 +244,7 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
     bool ambiguous = false;
     for (uint32_t w = 1; w <= max_w; ++w) {
         const uint32_t s = 1u + (uint32_t)kBlock * w;
-        const uint32_t passes_w = w <= 8u || passes < 2u ? passes : 2u;
+        const uint32_t passes_w = w <= 8u || passes < 2u ? passes : (max_passes < kPartSearch ? 1u : 2u);
         for (uint32_t pass = 0; pass < passes_w; ++pass) {
             const uint32_t X0 = X + 2048u * pass;
             uint32_t a = 0xFFFFFFFFu;
@@ -257,6 +272,89 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
     return ambiguous ? PartState{X, kPartWeak | kPartAmbig} : plain;
 }
 
+// One (width, pass) of that search, for the index route's staged variant: kPartEvid header bits 1 at stride 1 + 12 w from the 2048
+// positions behind X0.  Returns the state's position or ~0; depth = evidence bits the last candidates survived.
+__device__ __forceinline__ uint32_t part_try(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t* __restrict__ s_pm, uint32_t X0, uint32_t w,
+                                             uint32_t& depth, uint32_t& surv12) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t s = 1u + (uint32_t)kBlock * w;
+    uint32_t a = 0xFFFFFFFFu, k = 0;
+    surv12 = 0;
+    for (; k < kPartEvid; k += 4u) {
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) a &= part_bits(W, s_chunk, X0 + 32u * lane + (k + i) * s);
+        if (!__ballot(a != 0u)) break;
+        if (k == 8u) surv12 = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)__builtin_popcount(a)), 63);   // positions with 12 header bits 1 at this stride
+    }
+    depth = k;
+    const uint64_t hits = __ballot(a != 0u);
+    if (!hits) return ~0u;
+    const int l0 = __builtin_ctzll(hits);
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, l0);
+    const uint32_t r0 = 32u * (uint32_t)l0 + (uint32_t)__builtin_ctz(a0);
+    __builtin_amdgcn_wave_barrier();
+    s_pm[lane] = a;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t h = part_header_phase(s_pm, r0, s, w);
+    return h != ~0u ? X0 + h + kPartSkip * s : ~0u;
+}
+
+// The index route's search (k_chain_guess), staged by what the data show: (1) widths up to 8, the first 4096 positions -- two
+// thirds of the cuts of a stack with a width change every nine blocks end here, and header-dense data, where no run exists, pays
+// for no more than this; (2) the width whose candidates survived longest, if they survived 20 header bits (chance: 2^-20 per
+// candidate, 32 K candidates), over the rest of the range: runs of that width exist nearby; (3) wider widths, one pass each,
+// only if no small width showed 16 bits of evidence (pedestals, wide data).  A cut that ends without a run warms up instead.
+__device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t* __restrict__ s_pm, uint32_t X, uint32_t limit,
+                                                 uint32_t max_w, uint32_t reach) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t s_max = 1u + (uint32_t)kBlock * max_w;
+    const PartState plain{X, kPartWeak};
+#ifdef TRPX_PART_FORCE_WEAK
+    return plain;
+#endif
+    uint32_t passes = kPartSearch;
+    while (passes && (uint64_t)X + 2048ull * passes + (uint64_t)kPartEvid * s_max + 128u > (uint64_t)limit) --passes;   // too close to the frame's end
+    while (passes && 2048ull * passes + (uint64_t)kPartSkip * s_max > (uint64_t)reach) --passes;
+    if (passes == 0u) return plain;
+    part_fill(W, s_chunk, X);
+    {
+        const uint32_t a = lane < 4u ? part_bits(W, s_chunk, X + 32u * lane) : 0xFFFFFFFFu;
+        if (!__ballot(a != 0xFFFFFFFFu)) return PartState{X, 0u};            // inside a run of empty blocks
+    }
+    const uint32_t w1 = max_w < 8u ? max_w : 8u, p1 = passes < 2u ? passes : 2u;
+    uint32_t best_w = 0, best_d = 0, most12 = 0;
+    for (uint32_t w = 1; w <= w1; ++w)
+        for (uint32_t pass = 0; pass < p1; ++pass) {
+            uint32_t d, n12;
+            const uint32_t q = part_try(W, s_chunk, s_pm, X + 2048u * pass, w, d, n12);
+            if (q != ~0u) return PartState{q, w};
+            if (d > best_d) { best_d = d; best_w = w; }
+            most12 = n12 > most12 ? n12 : most12;
+        }
+    if (best_d >= 20u)
+        for (uint32_t pass = p1; pass < passes; ++pass) {
+            uint32_t d, n12;
+            const uint32_t q = part_try(W, s_chunk, s_pm, X + 2048u * pass, best_w, d, n12);
+            if (q != ~0u) return PartState{q, best_w};
+        }
+    if (best_d < 16u)
+        for (uint32_t w = w1 + 1u; w <= max_w; ++w) {
+            uint32_t d, n12;
+            const uint32_t q = part_try(W, s_chunk, s_pm, X, w, d, n12);
+            if (q != ~0u) return PartState{q, w};
+            most12 = n12 > most12 ? n12 : most12;
+        }
+    // How run-dominated?  What tells is how MANY of a pass's ~55 block starts carry 12 header bits 1 at one stride: ~45 where one
+    // block in sixty changes its width (synth-v1), ~28 at one in nine (eight 4096^2 int32 frames), ~22 in Poisson(3) counts, a
+    // handful in noise -- the deepest single candidate does not tell: runs of 28 blocks occur a few times per thousand cuts in
+    // Poisson(3) counts too.  Only the first kind gets the flag (a walk that stops instead of starting again, k_chain_walk):
+    // there a false chain may not merge for a whole part; in the others it merges within a few K bits, and a stopped part
+    // costs its repair a whole part's walk (71 of 4200 parts stopped: the repair launch 236 instead of ~20 us).
+    return most12 >= 40u ? PartState{X, kPartWeak | kPartRuns} : plain;
+}
+
 // Walks the chain from (pos, w) and counts the blocks that start in front of frame bit T; leaves the state at the first block
 // start >= T, and in ck[] the state and count at the first step end behind every `ck_every` bits (a state of the chain at a
 // block boundary: another chain that has merged with this one passes through it).  dense: more than one explicit header in 6
@@ -266,18 +364,39 @@ __device__ __forceinline__ PartState part_guess(PartWin& W, uint32_t* __restrict
 // have: it goes on from there with width 0 (what it counts in front of the merge is never used).  The steps are decode_frame.hip's (one per run of equal widths + the explicit header that ends it, the header
 // parsed on the scalar unit) without the position entries; the fast loop only takes steps whose 64 candidates all lie in
 // front of T and inside the window, the general step does the rest.
+//
+// STORE (the index route, see k_chain_walk): every step also leaves ent[j] = width of the block BEFORE the part's block j, for the 64
+// candidates of the step (one byte store per lane, no mask: what lies behind the step's last block is overwritten by the next
+// step, a wavefront's stores to one address arrive in program order), indices clamped to ent_cap - 1 -- a part that counts more
+// blocks than its entry array holds has no entries, which the caller sees from the count.  ent[count] = the width in front of
+// the block the walk stopped at.  ck == nullptr: no checkpoints and no density stop (ck_cap: entries ck[] has room for;
+// stop_dense: the serial walker's hand-over test, the old parts route only).
+template <bool STORE = false>
 __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w_prev, uint32_t T,
                                           uint32_t limit, uint32_t max_w, uint32_t& count, bool& bad, bool& dense,
-                                          PartCk* __restrict__ ck, uint32_t ck_every, uint32_t& n_ck, bool tolerant) {
+                                          PartCk* __restrict__ ck, uint32_t ck_every, uint32_t& n_ck, bool tolerant,
+                                          uint32_t ck_cap = kPartCk, bool stop_dense = true, uint8_t* __restrict__ ent = nullptr,
+                                          uint32_t ent_cap = 1u, bool abort_illegal = false, uint32_t prio_span = 0u) {
     const uint32_t lane = (uint32_t)lane_id();
     uint32_t b = 0, n_exp = 0, b_ref = 0, exp_ref = 0;
-    uint32_t ck_next = pos + ck_every;
+    uint32_t ck_next = ck ? pos + ck_every : 0xFFFFFFFFu;
+    [[maybe_unused]] const uint32_t capm1 = ent_cap - 1u;
     n_ck = 0;
     while (pos < T && !bad) {
         if (pos >= ck_next) {
-            if (n_ck < kPartCk && lane == 0) ck[n_ck] = PartCk{pos, w_prev, b};
-            n_ck = n_ck < kPartCk ? n_ck + 1u : n_ck;
+            if (n_ck < ck_cap && lane == 0) ck[n_ck] = PartCk{pos, w_prev, b};
+            n_ck = n_ck < ck_cap ? n_ck + 1u : n_ck;
             ck_next = pos + ck_every;
+            if (prio_span) {
+                // The SIMD's arbiter serves equal-priority waves oldest first: of the ~17 walkers of a CU the last to arrive finished
+                // at 115 - 137 us, the median at 65 (eight 4096 x 4096 frames, tools/chain_stamps.py) -- and a walker alone on its SIMD
+                // cannot use the issue slots the others left.  Priority by what is LEFT of the part keeps them level.
+                const uint32_t left = T - pos;
+                if (4u * left > 3u * prio_span) __builtin_amdgcn_s_setprio(3);
+                else if (2u * left > prio_span) __builtin_amdgcn_s_setprio(2);
+                else if (4u * left > prio_span) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             // (a chain that is not the frame's yet may look like anything until it has merged: a tolerant walk's count starts
             // at its sixteenth checkpoint)
             // (the weakparts test build never stops one: every part there has to get through k_part_repair)
@@ -285,7 +404,7 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
 #ifdef TRPX_PART_FORCE_WEAK
             constexpr bool stoppable = false;
 #else
-            const bool stoppable = !tolerant || n_ck >= 16u;
+            const bool stoppable = stop_dense && (!tolerant || n_ck >= 16u);
 #endif
             if (stoppable && b - b_ref >= 2048u && (n_exp - exp_ref) * 6u > b - b_ref) { dense = true; break; }
         }
@@ -308,82 +427,101 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
             uint32_t pw_max = pw_end - 63u * stride;
             uint32_t v_ls = __umul24(lane, stride);
             uint32_t s_bad = 0, t_first, t_h, t_t, t_p, t_a, t_bits;
-            asm volatile(
-                "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"
-                "s_cbranch_scc0 9f\n"
-                "1:\n\t"
-                "v_add_u32 %[p], %[pw], %[ls]\n\t"                 // this lane's candidate header
-                "v_lshrrev_b32 %[a], 3, %[p]\n\t"
-                "v_and_b32 %[a], 0x1ffffffc, %[a]\n\t"
-                "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_alignbit_b32 %[bits], v63, v62, %[p]\n\t"
-                "v_and_b32 %[a], 1, %[bits]\n\t"
-                "v_cmp_eq_u32 vcc, 0, %[a]\n\t"                   // lanes whose block has an explicit header (Terse.hpp:361)
-                "s_cbranch_vccz 5f\n\t"
-                "s_ff1_i32_b64 %[first], vcc\n\t"
-                "v_readlane_b32 %[h], %[bits], %[first]\n\t"
-                "s_bfe_u32 %[w], %[h], 0x30001\n\t"               // Terse.hpp:362
-                "s_cmp_lg_u32 %[w], 7\n\t"
-                "s_cbranch_scc0 6f\n\t"
-                "s_addc_u32 %[b], %[b], %[first]\n\t"             // b += first + 1 (SCC = 1)
-                "s_add_i32 %[nexp], %[nexp], 1\n\t"
-                "s_mul_i32 %[t], %[first], %[stride]\n\t"
-                "s_mul_i32 %[stride], %[w], 12\n\t"
-                "s_add_i32 %[pw], %[pw], %[t]\n\t"
-                "s_add_i32 %[stride], %[stride], 1\n\t"
-                "s_add_i32 %[pw], %[pw], %[stride]\n\t"
-                "s_add_i32 %[pw], %[pw], 3\n"                      // pos += first * stride + 4 + 12 w
-                "3:\n\t"
-                "v_mul_u32_u24 %[ls], %[stride], %[lane]\n\t"
-                "s_mul_i32 %[t], %[stride], 63\n\t"
-                "s_sub_i32 %[pwmax], %[pwend], %[t]\n"
-                "4:\n\t"
-                "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_branch 9f\n"
-                "5:\n\t"                                           // 64 blocks repeat the width
-                "s_lshl_b32 %[t], %[stride], 6\n\t"
-                "s_add_i32 %[pw], %[pw], %[t]\n\t"
-                "s_add_i32 %[b], %[b], 64\n\t"
-                "s_branch 4b\n"
-                "6:\n\t"                                           // widths >= 7: Terse.hpp:364-370
-                "s_bfe_u32 %[t], %[h], 0x20004\n\t"
-                "s_add_i32 %[w], %[t], 7\n\t"
-                "s_mul_i32 %[t], %[first], %[stride]\n\t"
-                "s_add_i32 %[pw], %[pw], %[t]\n\t"
-                "s_add_i32 %[pw], %[pw], 6\n\t"
-                "s_cmp_lg_u32 %[w], 10\n\t"
-                "s_cbranch_scc1 7f\n\t"
-                "s_bfe_u32 %[t], %[h], 0x60006\n\t"
-                "s_add_i32 %[w], %[t], 10\n\t"
-                "s_add_i32 %[pw], %[pw], 6\n"
-                "7:\n\t"
-                "s_cmp_gt_u32 %[w], %[maxw]\n\t"
-                "s_cbranch_scc1 8f\n\t"
-                "s_add_i32 %[b], %[b], %[first]\n\t"
-                "s_add_i32 %[b], %[b], 1\n\t"
-                "s_add_i32 %[nexp], %[nexp], 1\n\t"
-                "s_mul_i32 %[stride], %[w], 12\n\t"
-                "s_add_i32 %[pw], %[pw], %[stride]\n\t"
-                "s_add_i32 %[stride], %[stride], 1\n\t"
-                "s_branch 3b\n"
-                "8:\n\t"
-                "s_mov_b32 %[bad], 1\n"
+#define TRPX_PART_STEP_ASM(ST_STEP, ST_WIDTH)                                                                                  \
+                "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"                                                                             \
+                "s_cbranch_scc0 9f\n"                                                                                          \
+                "1:\n\t"                                                                                                       \
+                "v_add_u32 %[p], %[pw], %[ls]\n\t"                 /* this lane's candidate header */                          \
+                "v_lshrrev_b32 %[a], 3, %[p]\n\t"                                                                              \
+                "v_and_b32 %[a], 0x1ffffffc, %[a]\n\t"                                                                         \
+                "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"                                                                    \
+                ST_STEP                                              /* (in the LDS read's shadow) */                          \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+                "v_alignbit_b32 %[bits], v63, v62, %[p]\n\t"                                                                   \
+                "v_and_b32 %[a], 1, %[bits]\n\t"                                                                               \
+                "v_cmp_eq_u32 vcc, 0, %[a]\n\t"                   /* lanes whose block has an explicit header (Terse.hpp:361) */ \
+                "s_cbranch_vccz 5f\n\t"                                                                                        \
+                "s_ff1_i32_b64 %[first], vcc\n\t"                                                                              \
+                "v_readlane_b32 %[h], %[bits], %[first]\n\t"                                                                   \
+                "s_bfe_u32 %[w], %[h], 0x30001\n\t"               /* Terse.hpp:362 */                                          \
+                "s_cmp_lg_u32 %[w], 7\n\t"                                                                                     \
+                "s_cbranch_scc0 6f\n\t"                                                                                        \
+                "s_addc_u32 %[b], %[b], %[first]\n\t"             /* b += first + 1 (SCC = 1) */                               \
+                "s_add_i32 %[nexp], %[nexp], 1\n\t"                                                                            \
+                "s_mul_i32 %[t], %[first], %[stride]\n\t"                                                                      \
+                "s_mul_i32 %[stride], %[w], 12\n\t"                                                                            \
+                "s_add_i32 %[pw], %[pw], %[t]\n\t"                                                                             \
+                "s_add_i32 %[stride], %[stride], 1\n\t"                                                                        \
+                "s_add_i32 %[pw], %[pw], %[stride]\n\t"                                                                        \
+                "s_add_i32 %[pw], %[pw], 3\n"                      /* pos += first * stride + 4 + 12 w */                       \
+                "3:\n\t"                                                                                                       \
+                ST_WIDTH                                                                                                       \
+                "v_mul_u32_u24 %[ls], %[stride], %[lane]\n\t"                                                                  \
+                "s_mul_i32 %[t], %[stride], 63\n\t"                                                                            \
+                "s_sub_i32 %[pwmax], %[pwend], %[t]\n"                                                                         \
+                "4:\n\t"                                                                                                       \
+                "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"                                                                             \
+                "s_cbranch_scc1 1b\n\t"                                                                                        \
+                "s_branch 9f\n"                                                                                                \
+                "5:\n\t"                                           /* 64 blocks repeat the width */                            \
+                "s_lshl_b32 %[t], %[stride], 6\n\t"                                                                            \
+                "s_add_i32 %[pw], %[pw], %[t]\n\t"                                                                             \
+                "s_add_i32 %[b], %[b], 64\n\t"                                                                                 \
+                "s_branch 4b\n"                                                                                                \
+                "6:\n\t"                                           /* widths >= 7: Terse.hpp:364-370 */                        \
+                "s_bfe_u32 %[t], %[h], 0x20004\n\t"                                                                            \
+                "s_add_i32 %[w], %[t], 7\n\t"                                                                                  \
+                "s_mul_i32 %[t], %[first], %[stride]\n\t"                                                                      \
+                "s_add_i32 %[pw], %[pw], %[t]\n\t"                                                                             \
+                "s_add_i32 %[pw], %[pw], 6\n\t"                                                                                \
+                "s_cmp_lg_u32 %[w], 10\n\t"                                                                                    \
+                "s_cbranch_scc1 7f\n\t"                                                                                        \
+                "s_bfe_u32 %[t], %[h], 0x60006\n\t"                                                                            \
+                "s_add_i32 %[w], %[t], 10\n\t"                                                                                 \
+                "s_add_i32 %[pw], %[pw], 6\n"                                                                                  \
+                "7:\n\t"                                                                                                       \
+                "s_cmp_gt_u32 %[w], %[maxw]\n\t"                                                                               \
+                "s_cbranch_scc1 8f\n\t"                                                                                        \
+                "s_add_i32 %[b], %[b], %[first]\n\t"                                                                           \
+                "s_add_i32 %[b], %[b], 1\n\t"                                                                                  \
+                "s_add_i32 %[nexp], %[nexp], 1\n\t"                                                                            \
+                "s_mul_i32 %[stride], %[w], 12\n\t"                                                                            \
+                "s_add_i32 %[pw], %[pw], %[stride]\n\t"                                                                        \
+                "s_add_i32 %[stride], %[stride], 1\n\t"                                                                        \
+                "s_branch 3b\n"                                                                                                \
+                "8:\n\t"                                                                                                       \
+                "s_mov_b32 %[bad], 1\n"                                                                                        \
                 "9:\n"
-                : [pw] "+s"(pw), [b] "+s"(b), [nexp] "+s"(n_exp), [w] "+s"(w_prev), [stride] "+s"(stride), [pwmax] "+s"(pw_max),
-                  [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
-                  [a] "=&v"(t_a), [bits] "=&v"(t_bits)
-                : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w)
-                : "vcc", "scc", "memory", "v62", "v63");
+            if constexpr (STORE) {
+                uint32_t t_eo, v_wv = w_prev;
+                asm volatile(TRPX_PART_STEP_ASM("v_add_u32 %[eo], %[b], %[lane]\n\t"
+                                                "v_min_u32 %[eo], %[capm1], %[eo]\n\t"
+                                                "global_store_byte %[eo], %[wv], %[ebase]\n\t",
+                                                "v_mov_b32 %[wv], %[w]\n\t")
+                    : [pw] "+s"(pw), [b] "+s"(b), [nexp] "+s"(n_exp), [w] "+s"(w_prev), [stride] "+s"(stride), [pwmax] "+s"(pw_max),
+                      [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
+                      [a] "=&v"(t_a), [bits] "=&v"(t_bits), [eo] "=&v"(t_eo), [wv] "+v"(v_wv)
+                    : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w), [capm1] "s"(capm1), [ebase] "s"(ent)
+                    : "vcc", "scc", "memory", "v62", "v63");
+            } else {
+                asm volatile(TRPX_PART_STEP_ASM("", "")
+                    : [pw] "+s"(pw), [b] "+s"(b), [nexp] "+s"(n_exp), [w] "+s"(w_prev), [stride] "+s"(stride), [pwmax] "+s"(pw_max),
+                      [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
+                      [a] "=&v"(t_a), [bits] "=&v"(t_bits)
+                    : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w)
+                    : "vcc", "scc", "memory", "v62", "v63");
+            }
+#undef TRPX_PART_STEP_ASM
             pos = pw - base8 + 32u * (uint32_t)W.c_lo - W.frame_sh;
             if (s_bad) {
                 if (!tolerant) { bad = true; break; }
+                if (abort_illegal) { dense = true; break; }                               // (a chain that is not the frame's: see k_chain_walk)
                 w_prev = 0u;                                                              // (pos: behind the illegal header)
             }
         }
         if (pos >= T) break;
         if (pos > limit) { bad = true; break; }
+        if (pos >= ck_next) continue;                                             // (the fast steps stopped for a checkpoint: no general step)
         stride = 1u + (uint32_t)kBlock * w_prev;
         {
             const uint32_t need_lo = (W.frame_sh + pos) >> 5;
@@ -398,6 +536,10 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
         const uint64_t valid = kT >= 64u ? ~0ull : ((1ull << kT) - 1ull);
         const uint64_t stop = ~(__ballot((bits & 1u) != 0u) & valid);
         const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        if constexpr (STORE) {                                                // the width in front of this step's blocks
+            const uint32_t n_done = first < kT ? first + 1u : kT;
+            if (lane < n_done) ent[b + lane < capm1 ? b + lane : capm1] = (uint8_t)w_prev;
+        }
         if (first < kT) {                                                     // explicit header at candidate `first`
             const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)first);
             uint32_t w = (eb >> 1) & 7u, hl = 4;                              // Terse.hpp:362-370
@@ -407,6 +549,11 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
             }
             if (w > max_w) {
                 if (!tolerant) { bad = true; break; }
+                if (abort_illegal) {                                          // (stops behind the illegal header, as the fast steps do)
+                    pos += first * stride + hl; w_prev = 0u; b += first + 1u;
+                    dense = true;
+                    break;
+                }
                 w = 0u;
             }
             pos += first * stride + hl + (uint32_t)kBlock * w;
@@ -420,6 +567,9 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
         if (pos > limit) { bad = true; break; }
     }
     count = b;
+    if constexpr (STORE) {
+        if (lane == 0) ent[b < capm1 ? b : capm1] = (uint8_t)w_prev;
+    }
 }
 
 // Counts the blocks of a part again from the true state (pos, w) -- general steps only -- until the chain passes through a
@@ -708,6 +858,585 @@ hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t s
     hipLaunchKernelGGL(k_part_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartState*>(states),
                        static_cast<const PartWalk*>(walks), static_cast<const PartFix*>(fixes), a.geom, P, a.frame_offsets, (uint64_t)a.terse_bytes,
                        a.parts, a.defer, a.status);
+    return hipGetLastError();
+}
+
+// =================================================================================================================================
+// The INDEX route for large frames (round 5): one walk, then the extraction with the widths given.
+//
+// The parts route above walks every block twice -- k_part_walk counts, k_decode_parts' walker walks again to extract -- because a
+// part's pixels cannot be placed before the blocks in front of it are counted.  Here the counting walk leaves what it saw: per
+// block one byte, the width in front of it, in a per-part entry array (relative block numbers: the part's first block is not
+// known yet).  Once k_chain_resolve has the block numbers, k_chain_index turns the entries into the decode index the extraction
+// kernels consume (widths[] by absolute block, bit offset of every 256th block: encode_kernels.hpp) -- 35 vector instructions per
+// 64 BLOCKS, no dependent chain -- and the frames are extracted as if the caller had brought the index (k_unpack_tiles /
+// k_decode_frames_indexed).  With the decoder's grain out of the way the walk's parts are SMALL (about kChainBlocks blocks): a
+// serial walker is a latency chain, ~130 ns per run of equal widths whatever else runs on the SIMD, so the walk's time is the
+// longest part's, and ten times more, ten times shorter chains cost nothing but their start states:
+//
+//   k_chain_guess   a start state inside a run of equal widths behind every cut X_p = p * L (part_guess, as above), searched over at
+//                   most half a part; the frame's last cut lies kChainTail bits in front of its end.
+//   k_chain_walk    one wavefront per part but the last.  A part whose cut found no run -- header-dense data -- WARMS UP: it starts
+//                   kChainWarm bits in front of its cut from a plain guess, tolerant, and takes the state in which that chain
+//                   crosses the cut (false chains merge with the frame's at the first explicit header they meet on a block start:
+//                   a median of 94 blocks in Poisson(3) counts, tools/merge_stats.py); the part in front of it arrives at the same
+//                   block start if it is on the frame's chain.  Then the counting walk with the entry stores (part_walk<true>).
+//   k_chain_repair  open links (OUT_(p-1) != the state part p started in): part p counted again from OUT_(p-1) until that chain
+//                   passes through a checkpoint of the part's own walk, as above.
+//   k_chain_resolve one wavefront per frame: S_0 true, links closed or repaired => by induction every part's start, count and end
+//                   are the frame's chain's; prefix sums; the part table.  pad bit 0: the part's entries are the true chain's (it
+//                   started in the state it was walked from, and they fit).
+//   k_chain_index   one wavefront per part: entries -> widths[b0 ..), group offsets by a prefix sum over header + payload lengths,
+//                   the end checked against the next part's start.  Parts without entries -- repaired, overflowed (runs of empty
+//                   blocks: 1 bit each, 64 per step), the frame's last part (whose last block may be partial: only the block
+//                   count tells where the frame ends) -- are walked from their true start, by count, writing the index directly.
+//
+// A frame where this does not work out is listed for the position-parallel walk (decode_seg.hip), which writes the same index;
+// the extraction follows for all frames at once.  Guesses, warm-ups and repairs only ever steer the speed: every part's end is
+// checked against its successor's start, the last one against S_f = 1 + bits/8 (Terse.hpp:547).
+// =================================================================================================================================
+#ifndef TRPX_CHAIN_WAVES
+#define TRPX_CHAIN_WAVES 4352
+#endif
+constexpr uint32_t kChainCk = 64;              // checkpoints per part
+constexpr uint32_t kChainTail = 2048;          // bits of the frame's last part (walked by count in k_chain_index)
+constexpr uint32_t kChainPatience = 8192;      // bits into a part after which a walk that reads an illegal width stops instead of starting again
+constexpr uint32_t kChainEntSlack = 80;
+
+// Parts per frame: as many walkers as the GPU holds at once (8 KB of LDS each: 19 per CU) -- a second round of a few hundred
+// stragglers doubled k_chain_walk's time (eight 4096 x 4096 frames, 5464 parts: 146 us; tools/chain_stamps.py) --, of 1 K ..
+// 16 K blocks each; + the tail part.
+uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames) {
+    if (g.n_blocks <= kPartMaxBlocks || n_frames == 0) return 1u;
+#ifdef TRPX_DIAGNOSTICS
+    static const uint64_t waves = getenv("TRPX_CHAIN_WAVES") ? (uint64_t)atoi(getenv("TRPX_CHAIN_WAVES")) : (uint64_t)TRPX_CHAIN_WAVES;
+#else
+    constexpr uint64_t waves = TRPX_CHAIN_WAVES;
+#endif
+    const uint64_t lo = ((uint64_t)g.n_blocks + kPartBlocks - 1u) / kPartBlocks, hi = (uint64_t)g.n_blocks / 1024u;
+    uint64_t n = waves / n_frames;
+    n = n < lo ? lo : (n > hi ? hi : n);
+    return (uint32_t)(n < 3u ? 4u : n + 1u);
+}
+__host__ __device__ inline uint32_t chain_ent_cap(uint32_t n_blocks, uint32_t P) { return 2u * ((n_blocks + P - 1u) / P) + kChainEntSlack; }
+struct ChainFix {                              // what k_chain_repair leaves per (frame, part 1 <= p < P - 1)
+    uint32_t state;                            // 0: link closed, nothing done; 1: merged into the part's walk; 2: walked to T_p on its own; 3: failed
+    uint32_t cnt, o_pos, o_w;                  // the part's block count (and, state 2, its end state) from the true start
+    uint32_t b_merge, ck_cnt;                  // state 1: the repair's block b_merge is the part's own walk's block ck_cnt (a checkpoint)
+    uint32_t n_fix;                            // entries the repair left for its blocks [0, b_merge] (0: they did not fit)
+    uint32_t pad;
+};
+struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, total; };
+static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
+    ChainWs w;
+    w.states = 0;
+    w.walks = align_up(w.states + n_frames * P * sizeof(PartState), 256);
+    w.fixes = align_up(w.walks + n_frames * P * sizeof(PartWalk), 256);
+    w.cks = align_up(w.fixes + n_frames * P * sizeof(ChainFix), 256);
+    w.ents = align_up(w.cks + n_frames * P * kChainCk * sizeof(PartCk), 256);
+    w.fixents = align_up(w.ents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);
+    w.total = align_up(w.fixents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);   // (a repair's entries: as many as a walk's)
+    return w;
+}
+size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames) {
+    const size_t P = chain_parts_per_frame(g, n_frames);
+    return P > 1 ? chain_ws_layout(g, n_frames, P).total : 0;
+}
+
+// The frame's cuts: X_p = p * L for p < P, the last one kChainTail bits (or a sixteenth of a small frame) in front of the end.
+__device__ __forceinline__ PartFrame chain_frame(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                 const uint64_t* __restrict__ frame_offsets, uint32_t frame, uint32_t P) {
+    PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
+    if (!f.ok) return f;
+    const uint32_t tail = f.limit > 16u * kChainTail ? kChainTail : f.limit / 16u;
+    f.L = (f.limit - tail + (P - 2u)) / (P - 1u);
+    f.ok = f.L >= 1024u && tail > P;                                        // (a frame of a few bits per part: another route)
+    return f;
+}
+
+__global__ __launch_bounds__(kWave) void k_chain_guess(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                       const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                       PartState* __restrict__ states) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    __shared__ uint32_t s_pm[kWave + 2];
+    const uint32_t frame = blockIdx.x / P, p = blockIdx.x % P;
+    const uint32_t lane = (uint32_t)lane_id();
+    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    if (lane < 2u) s_pm[kWave + lane] = 0u;
+    PartState s{0u, 0u};                                                      // a frame starts at bit 0 with width 0 (Terse.hpp:359, :505)
+    if (p != 0u) {
+        PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
+        if (!f.ok) s = PartState{0u, kPartWeak};
+        else {
+            const uint32_t X = p * f.L;
+            // the search stays inside the part's first half: a start state lies in front of the next cut
+            const uint32_t reach = p + 1u < P ? f.L / 2u : (f.limit - X) / 2u;
+            s = chain_guess(f.W, s_chunk, s_pm, X, f.limit, max_w, reach);
+        }
+    }
+    if (lane == 0) states[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                      const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                      uint32_t ent_cap, const PartState* __restrict__ states,
+                                                      PartWalk* __restrict__ walks, PartCk* __restrict__ cks, uint8_t* __restrict__ ents,
+                                                      [[maybe_unused]] uint32_t* __restrict__ stamps) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    const uint32_t frame = blockIdx.x / (P - 1u), p = blockIdx.x % (P - 1u);
+    const uint32_t lane = (uint32_t)lane_id();
+#ifdef TRPX_CHAIN_STAMPS
+    const uint64_t st_a = __builtin_amdgcn_s_memrealtime();
+    uint64_t st_b = st_a, st_c = st_a;
+#endif
+    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    const uint64_t slot = (uint64_t)frame * P + p;
+    PartWalk r{};
+    r.flags = 1u;
+    PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
+    const PartState s = states[slot], t = states[slot + 1u];
+#ifdef TRPX_CHAIN_STAMPS
+    if (t.pos + s.pos == 0xFFFFFFFFu) return;                                 // (the loads have arrived)
+    st_b = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (f.ok && t.pos > s.pos && t.pos < f.limit) {
+        uint32_t pos = s.pos, w = s.w & ~kPartFlags, cnt = 0, n_ck = 0;
+        bool bad = false, dense = false, stopped = false;
+        const uint32_t X = pos;
+        // (how long a walk that reads illegal widths keeps starting again: for ever where the cut found no runs at all -- header-dense
+        // data: false chains merge within a few K bits, and a stopped part costs its repair a whole part's walk, the repair launch's
+        // critical path: 233 against 15 us for 200 x (1030 x 1065) Poisson(3) counts --, kChainPatience bits where runs lie nearby or
+        // the start was a run guess, which is then a wrong one: run-dominated data)
+        const uint32_t patience = (s.w & kPartWeak) != 0u && (s.w & kPartRuns) == 0u ? 0xFFFFFFFFu : kChainPatience;
+#ifdef TRPX_CHAIN_STAMPS
+        st_c = __builtin_amdgcn_s_memrealtime();
+#endif
+        // A cut without a run to start in (header-dense data; the weakparts test build: every cut) starts ON the cut from a plain
+        // guess: the chain is not the frame's until it has merged with it -- at the first explicit header it meets on a block start,
+        // a median of 94 blocks in Poisson(3) counts (tools/merge_stats.py) -- and the link in front of the part is open: the
+        // repair counts from the true state to the first checkpoint behind the merge, a few hundred blocks, in parallel for all
+        // parts.  (A warm-up stretch in FRONT of the cut, so that the chain arrives merged -- round 5's first version, 16 K bits --
+        // closed 95 % of such links and cost every wavefront 28 .. 52 us of walking on a false chain, which takes a step every
+        // other block: more than the repairs of all links together.)
+        // A width the pixel type does not have says the chain is not the frame's yet (2 - 6 % of a false chain's explicit headers
+        // read one; a true chain's none).  Early in the part the walk RESTARTS behind it -- count, checkpoints and entries begin
+        // again: what they held was not the frame's --; kChainPatience bits into the part it STOPS: in run-dominated data a
+        // false chain may not merge for a whole part, at five times a true chain's time per bit, and the launch ends with its
+        // slowest wavefront (one such part of 4200: 227 against 50 us); the repair then counts the part from its true start.
+        for (;;) {
+            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);         // (wave-uniform by construction: the steps' state lives in scalar registers)
+            w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+            r.s_pos = pos; r.s_w = w;
+            const uint32_t span = t.pos - pos;
+            const uint32_t every = span / (kChainCk - 8u) > 4096u ? span / (kChainCk - 8u) : 4096u;
+            dense = false;
+            part_walk<true>(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cnt, bad, dense, cks + slot * kChainCk, every, n_ck, p != 0u,
+                            kChainCk, false, ents + slot * ent_cap, ent_cap, p != 0u, t.pos - X);
+            if (!dense || bad) break;
+            if (pos >= t.pos || pos - X >= patience) {
+                stopped = true;
+#ifdef TRPX_PART_STATS
+                if (lane == 0) printf("walk stopped: frame %u part %u guess flags %x start %u at %u (target %u) patience %u cnt %u\n", frame, p, s.w >> 28, X, pos, t.pos, patience, cnt);
+#endif
+                break;
+            }
+            w = 0u;                                                           // (pos: behind the illegal header)
+        }
+        r.o_pos = pos; r.o_w = w; r.cnt = cnt; r.n_ck = n_ck;
+        r.flags = (bad ? 1u : 0u) | (cnt + 1u > ent_cap - 1u ? 8u : 0u) | (stopped ? 16u : 0u);   // 8: more blocks than entries; 16: stopped on a false chain
+    }
+    if (lane == 0) walks[slot] = r;
+#ifdef TRPX_CHAIN_STAMPS
+    if (lane == 0) {       // diagnostic build (tools/chain_stamps.py): a status block of 16 + 8 * parts words
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t st_d = __builtin_amdgcn_s_memrealtime();
+        uint32_t* o = stamps + 16 + 8 * slot;
+        o[0] = (uint32_t)st_a; o[1] = (uint32_t)(st_b - st_a); o[2] = (uint32_t)(st_c - st_b); o[3] = (uint32_t)(st_d - st_c);
+        o[4] = f.W.n_fill; o[5] = f.W.t_fill; o[6] = r.cnt; o[7] = r.n_ck;
+    }
+#endif
+}
+
+// The blocks of a part counted again from the true state (pos, w), checkpoint by checkpoint of the part's own walk: fast steps to
+// the next checkpoint's position (part_walk: it stops at the first block start at or behind it), and if the chain arrives IN the
+// checkpoint's state the two have merged -- the rest of that walk is this chain's.  Leaves the entries of the blocks it counted in
+// fix[] (part_walk<true>) as long as they fit.  Returns the ChainFix state.
+__device__ __forceinline__ uint32_t chain_rewalk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w, uint32_t T,
+                                                 uint32_t limit, uint32_t max_w, const PartCk* __restrict__ ck, uint32_t n_ck,
+                                                 uint32_t walk_cnt, uint8_t* __restrict__ fix, uint32_t fix_cap, ChainFix& x) {
+    uint32_t b = 0, k = 0;
+    bool fits = true, bad = false, dense = false;
+    for (;;) {
+        while (k < n_ck && ck[k].pos <= pos) {
+            const PartCk c = ck[k];
+            if (c.pos == pos && c.w == w) {                                   // (starts in a checkpoint: nothing to count)
+                x.b_merge = b; x.ck_cnt = c.cnt; x.cnt = b + (walk_cnt - c.cnt); x.n_fix = fits ? b + 1u : 0u;
+                return 1u;
+            }
+            ++k;
+        }
+        const uint32_t target = k < n_ck ? ck[k].pos : T;
+        uint32_t cnt = 0, n0 = 0;
+        if (fits && b + 160u < fix_cap)
+            part_walk<true>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false, fix + b, fix_cap - b);
+        else
+            part_walk<false>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false);
+        if (bad) return 3u;
+        b += cnt;
+        fits = fits && b + 1u < fix_cap;
+        if (k >= n_ck) break;                                                 // at T on its own
+    }
+    x.cnt = b; x.o_pos = pos; x.o_w = w; x.b_merge = b; x.ck_cnt = 0u; x.n_fix = fits ? b + 1u : 0u;
+    return 2u;
+}
+
+// One wavefront per part 1 <= p <= P - 2: the link INTO part p.  A part whose walk stopped on a false chain (flag 16) is counted as
+// a whole from the true end of the part in front (state 2: nothing to merge into), and the same wavefront goes on into the parts
+// behind it for as long as they are stopped parts or do not start where it arrives: their own wavefronts, which cannot know the
+// true end of a stopped part, do nothing.  Every part's ChainFix is written by exactly one wavefront.
+__global__ __launch_bounds__(kWave) void k_chain_repair(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                        const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                        const PartState* __restrict__ states, const PartWalk* __restrict__ walks,
+                                                        const PartCk* __restrict__ cks, ChainFix* __restrict__ fixes,
+                                                        uint8_t* __restrict__ fixents, uint32_t fix_cap) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    const uint32_t frame = blockIdx.x / (P - 1u), p = blockIdx.x % (P - 1u);
+    const uint32_t lane = (uint32_t)lane_id();
+    if (p == 0u) return;                                                      // (part 0 starts in the true state)
+    const uint64_t slot0 = (uint64_t)frame * P;
+    const PartWalk prev = walks[slot0 + p - 1u];
+    if ((prev.flags & 16u) != 0u) return;                                     // the wavefront that counts the stopped part in front goes on into this one
+    PartWalk mine = walks[slot0 + p];
+    uint32_t pos = prev.o_pos, w = prev.o_w;                                  // the true end of the part in front (if ITS start was true: k_chain_resolve)
+    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
+#ifdef TRPX_PART_STATS
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (uint32_t cur = p;;) {
+        ChainFix x{};
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);             // (wave-uniform by construction)
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        const bool open = !(pos == mine.s_pos && w == mine.s_w) || (mine.flags & 16u) != 0u;
+        if (open && (prev.flags & 1u) == 0u) {
+            x.state = 3u;
+            const PartState t = states[slot0 + cur + 1u];
+            if (f.ok && (mine.flags & 1u) == 0u && pos < t.pos && t.pos < f.limit) {
+                const uint32_t n_ck = (mine.flags & 16u) != 0u ? 0u : (mine.n_ck < kChainCk ? mine.n_ck : kChainCk);   // (a stopped walk: nothing to merge into)
+                x.state = chain_rewalk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cks + (slot0 + cur) * kChainCk, n_ck, mine.cnt,
+                                       fixents + (slot0 + cur) * (uint64_t)fix_cap, fix_cap, x);
+                if (x.state == 1u && (mine.flags & 8u) != 0u) x.n_fix = 0u;  // (the part's own entries did not fit: nothing to splice onto)
+#ifdef TRPX_PART_STATS
+                if (x.state == 3u && lane == 0)
+                    printf("repair failed in its walk: frame %u part %u of %u at %u/%u target %u limit %u, own walk %u/%u -> %u/%u cnt %u n_ck %u flags %u\n",
+                           frame, cur, P, pos, w, t.pos, f.limit, mine.s_pos, mine.s_w, mine.o_pos, mine.o_w, mine.cnt, mine.n_ck, mine.flags);
+#endif
+            }
+        }
+        if (lane == 0) fixes[slot0 + cur] = x;
+#ifdef TRPX_PART_STATS
+        {
+            const uint64_t t_now = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && t_now - t_start > 8000u)
+                printf("slow repair: frame %u part %u (from %u) %u us: state %u cnt %u merge at %u (own block %u), own walk cnt %u n_ck %u flags %u start %u/%u, true start %u\n", frame, cur, p,
+                       (uint32_t)(t_now - t_start) / 100u, x.state, x.cnt, x.b_merge, x.ck_cnt, mine.cnt, mine.n_ck, mine.flags, mine.s_pos, mine.s_w, prev.o_pos);
+        }
+#endif
+        // on into the next part?  only behind a stopped part that this wavefront has counted to its end
+        if (x.state != 2u || (mine.flags & 16u) == 0u || cur + 1u > P - 2u) break;
+        ++cur;
+        mine = walks[slot0 + cur];                                            // (pos, w: the true end of the part just counted)
+    }
+}
+
+// list[0] = count, list[1 + i] = frame (bit 31 clear: the position-parallel walk may look for runs).
+__global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restrict__ walks, const ChainFix* __restrict__ fixes, FrameGeom g,
+                                                         uint32_t P, PartDesc* __restrict__ parts, uint32_t* __restrict__ list,
+                                                         uint32_t* __restrict__ status) {
+    const uint32_t frame = blockIdx.x, lane = (uint32_t)lane_id();
+    const PartWalk* __restrict__ wf = walks + (uint64_t)frame * P;
+    const ChainFix* __restrict__ xf = fixes + (uint64_t)frame * P;
+    PartDesc* __restrict__ pf = parts + (uint64_t)frame * P;
+    bool ok = true;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < P - 1u; base += kWave) {
+        const uint32_t p = base + lane;
+        const bool valid = p < P - 1u;
+        PartWalk r{};
+        ChainFix x{};
+        bool good = true, own = true, spliced = false;
+        uint32_t cnt = 0;
+        PartState st{0u, 0u}, en{0u, 0u};                                     // the part's true start and end states
+        if (valid) {
+            // (Everything is loaded up front, with clamped indices, and combined without branches: fixes[] of a frame's part 0 is
+            // never written and never used -- every use is masked by p.  A first version with the loads inside nested divergent
+            // ifs marked EVERY frame for the other route in the optimised build and none with a printf in the loop.)
+            const uint32_t p1 = p > 0u ? p - 1u : 0u;
+            r = wf[p];
+            x = xf[p];
+            const PartWalk q = wf[p1];
+            const ChainFix xq = xf[p1];
+            if (p == 0u) x = ChainFix{};
+            // The true end of the part in front: its walk's; of a part whose walk STOPPED on a false chain (flag 16), its repair's
+            // (state 2) -- and this part's ChainFix was then left by that same wavefront, from that true end (k_chain_repair).
+            // A part in front whose walk ran to the cut on a false chain without reading an illegal width (its repair met nothing:
+            // state 2 with another end than the walk's) leaves this part's link judged from a false state: the other route.
+            const bool q_stopped = p > 0u && (q.flags & 16u) != 0u;
+            const bool q_lost = p > 1u && !q_stopped && xq.state == 2u && !(xq.o_pos == q.o_pos && xq.o_w == q.o_w);
+            const PartState te = q_stopped ? PartState{xq.o_pos, xq.o_w} : PartState{q.o_pos, q.o_w};
+            const bool closed = p == 0u || (te.pos == r.s_pos && te.w == r.s_w);
+            const bool use_own = closed && (r.flags & 16u) == 0u;             // starts in the state it was walked from, on the frame's chain
+            const bool use_fix = !use_own && (x.state == 1u || x.state == 2u);
+            good = (r.flags & 1u) == 0u && (use_own || use_fix) && !q_lost && !(q_stopped && xq.state != 2u);
+            st = use_own ? PartState{r.s_pos, r.s_w} : te;
+            cnt = use_own ? r.cnt : x.cnt;
+            en = use_own || x.state == 1u ? PartState{r.o_pos, r.o_w} : PartState{x.o_pos, x.o_w};
+            own = use_own && (r.flags & 8u) == 0u;
+            spliced = use_fix && x.n_fix != 0u;                               // (entries: the repair's up to the merge, the walk's own behind it)
+            good = good && cnt >= 1u;
+        }
+        ok = ok && !__ballot(valid && !good);
+#ifdef TRPX_PART_STATS
+        {   // diagnostic build: status[4..7] = bad walks, repaired links, failed repairs, parts without entries
+            const uint32_t n4 = (uint32_t)__builtin_popcountll(__ballot(valid && (r.flags & 1u) != 0u));
+            const uint32_t n5 = (uint32_t)__builtin_popcountll(__ballot(valid && p > 0u && (x.state == 1u || x.state == 2u)));
+            const uint32_t n6 = (uint32_t)__builtin_popcountll(__ballot(valid && p > 0u && x.state == 3u));
+            const uint32_t n7 = (uint32_t)__builtin_popcountll(__ballot(valid && good && !own && !spliced));
+            if (lane == 0) { atomicAdd(status + 4, n4); atomicAdd(status + 5, n5); atomicAdd(status + 6, n6); atomicAdd(status + 7, n7); }
+        }
+#endif
+        const uint32_t c = valid && good ? cnt : 0u;
+        const uint32_t inc = wave_inclusive_scan(c);
+        if (valid && good) {
+            PartDesc d;
+            d.frame = frame; d.b0 = running + inc - c; d.b1 = d.b0 + c;
+            d.pos0 = st.pos; d.w0 = st.w; d.pos1 = en.pos; d.w1 = en.w; d.pad = own ? 1u : (spliced ? 2u : 0u);
+            pf[p] = d;
+            if (p == P - 2u) {                                                // the frame's last part starts where this one ends
+                PartDesc e;
+                e.frame = frame; e.b0 = d.b1; e.b1 = g.n_blocks; e.pos0 = en.pos; e.w0 = en.w; e.pos1 = 0u; e.w1 = 0u; e.pad = 0u;
+                pf[P - 1u] = e;
+            }
+        }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (tot >= g.n_blocks - running) ok = false;                          // (the last part holds at least the frame's last block)
+        running += ok ? tot : 0u;
+    }
+    if (!ok) {
+#ifdef TRPX_PART_STATS
+        if (frame < 3u && lane == 0) printf("resolve: frame %u not ok, running %u of %u blocks, P %u\n", frame, running, g.n_blocks, P);
+#endif
+        __builtin_amdgcn_s_waitcnt(0);
+        for (uint32_t p = lane; p < P; p += kWave) {
+            PartDesc d{};
+            d.frame = frame;
+            pf[p] = d;                                                        // b1 <= b0: nothing to do for k_chain_index
+        }
+        if (lane == 0) {
+            list[1u + atomicAdd(&list[0], 1u)] = frame;
+            atomicAdd(status + 2, 1u);                                        // status[2]: frames the index route handed to the position-parallel walk
+        }
+    }
+}
+
+// Walks `nb` blocks from (pos, w_prev) -- general steps, Terse.hpp:360-372 -- and writes their widths to wf[0 .. nb) and the bit
+// offset of every block whose frame number b0 + i is a multiple of 256 to tf[(b0 + i) / 256].  at_end: the last of them is the
+// frame's last block (nb_last values).  Returns false on a width the pixel type does not have or a chain that leaves the frame.
+__device__ __forceinline__ bool chain_walk_abs(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w_prev, uint32_t nb,
+                                               bool at_end, uint32_t nb_last, uint32_t limit, uint32_t max_w, uint8_t* __restrict__ wf,
+                                               uint64_t* __restrict__ tf, uint32_t b0) {
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t b = 0;
+    while (b < nb) {
+        const uint32_t stride = 1u + (uint32_t)kBlock * w_prev;
+        {
+            const uint32_t need_lo = (W.frame_sh + pos) >> 5;
+            const uint32_t need_hi = ((W.frame_sh + pos + 63u * stride) >> 5) + 2u;
+            if ((int32_t)need_lo < W.c_lo || (int32_t)need_hi > W.c_hi) part_fill(W, s_chunk, pos);
+        }
+        const uint32_t lpos = pos + lane * stride;
+        const uint32_t bits = part_bits(W, s_chunk, lpos);
+        const uint32_t left = nb - b;
+        const uint64_t valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+        const uint64_t stop = ~(__ballot((bits & 1u) != 0u) & valid);
+        const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        uint32_t e_w = w_prev, new_pos, new_b;
+        if (first < left && first < 64u) {                                    // explicit header at block b + first
+            const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)first);
+            uint32_t w = (eb >> 1) & 7u, hl = 4;                              // Terse.hpp:362-370
+            if (w == 7u) {
+                w += (eb >> 4) & 3u; hl = 6;
+                if (w == 10u) { w += (eb >> 6) & 63u; hl = 12; }
+            }
+            if (w > max_w) return false;
+            e_w = w;
+            const uint32_t nbv = at_end && b + first + 1u == nb ? nb_last : (uint32_t)kBlock;
+            new_pos = pos + first * stride + hl + nbv * w;
+            new_b = b + first + 1u;
+        } else {                                                              // they all repeat the width
+            const uint32_t cnt = left < 64u ? left : 64u;
+            new_pos = pos + cnt * stride;
+            if (at_end && b + cnt == nb) new_pos = pos + (cnt - 1u) * stride + 1u + nb_last * w_prev;
+            new_b = b + cnt;
+        }
+        const uint32_t n_done = new_b - b;
+        if (lane < n_done) {
+            wf[b + lane] = (uint8_t)(lane < first ? w_prev : e_w);
+            if (((b0 + b + lane) & (uint32_t)(kTileBlocks - 1)) == 0u) tf[(b0 + b + lane) / (uint32_t)kTileBlocks] = lpos;
+        }
+        pos = new_pos; w_prev = e_w; b = new_b;
+        if (pos > limit) return false;
+    }
+    return true;
+}
+
+// Entries j .. j + 3 of a part as one dword: its own walk's (E), or -- a repaired part -- the repair's up to the block where the
+// chains merged and the walk's own, shifted, behind it.  (Unaligned dword loads; bytes behind the part's last entry are the
+// neighbour's or slack and are not used.)
+__device__ __forceinline__ uint32_t chain_ent4(const uint8_t* __restrict__ E, const uint8_t* __restrict__ F, uint32_t j, uint32_t b_merge,
+                                               int32_t shift) {
+    uint32_t q;
+    if (!F || j > b_merge) { __builtin_memcpy(&q, E + (int64_t)j + (F ? shift : 0), 4); return q; }
+    __builtin_memcpy(&q, F + j, 4);
+    if (j + 3u > b_merge) {
+        uint32_t e;
+        __builtin_memcpy(&e, E + (int64_t)j + shift, 4);
+        const uint32_t keep = 0xFFFFFFFFu >> (8u * (3u - (b_merge - j)));   // bytes j .. b_merge from the repair
+        q = (q & keep) | (e & ~keep);
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                       const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w, uint32_t P,
+                                                       uint32_t ent_cap, PartDesc* __restrict__ parts, uint8_t* __restrict__ ents,
+                                                       const ChainFix* __restrict__ fixes, const uint8_t* __restrict__ fixents,
+                                                       uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                       uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    const uint32_t lane = (uint32_t)lane_id();
+    const PartDesc d = parts[blockIdx.x];
+    if (d.b1 <= d.b0) return;                                                 // the frame took another route
+    const uint32_t frame = d.frame, cnt = d.b1 - d.b0;
+    const bool at_end = d.b1 == g.n_blocks;
+    const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);
+    uint8_t* __restrict__ wf = widths + (uint64_t)frame * g.n_blocks + d.b0;
+    uint64_t* __restrict__ tf = tile_off + (uint64_t)frame * g.n_tiles;
+    const uint64_t fo = frame_offsets[frame], fe = frame_offsets[frame + 1];
+    bool done = false, have = (d.pad & 3u) != 0u;
+    uint8_t* __restrict__ E = ents + (uint64_t)blockIdx.x * ent_cap;
+    if (!have && !at_end && cnt + 2u < ent_cap) {
+        // No entries of the true chain (a repair's did not fit, the walk's own overflowed into ...): the part's counting walk once
+        // more, fast steps, from its true start to its true end -- into the part's own entry array.
+        if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+        PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
+        if (f.ok && d.pos0 < d.pos1 && d.pos1 < f.limit) {
+            uint32_t pos = d.pos0, w = d.w0, c2 = 0, n0 = 0;
+            bool bad = false, dense = false;
+            part_walk<true>(f.W, s_chunk, pos, w, d.pos1, f.limit, max_w, c2, bad, dense, nullptr, 0u, n0, false, 0u, false, E, ent_cap);
+            __builtin_amdgcn_s_waitcnt(0);                                    // (the entries are read back below)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            have = !bad && c2 == cnt && pos == d.pos1 && w == d.w1;
+        }
+    }
+    if (have && !at_end) {
+        // ---- entries -> index: lengths from the widths (Terse.hpp:517-535), positions by a prefix sum; 256 blocks per step, four
+        // consecutive ones per lane (one dword of entries in, one dword of widths out), the next step's entries requested first ----
+        const uint8_t* __restrict__ F = nullptr;
+        uint32_t b_merge = 0;
+        int32_t shift = 0;
+        if ((d.pad & 2u) != 0u) {
+            const ChainFix x = fixes[blockIdx.x];
+            F = fixents + (uint64_t)blockIdx.x * ent_cap;
+            b_merge = x.b_merge; shift = (int32_t)x.ck_cnt - (int32_t)x.b_merge;
+        }
+        uint32_t pos = d.pos0;
+        bool bad = false;
+        uint32_t q = chain_ent4(E, F, 4u * lane, b_merge, shift), w_last = 0;
+        const uint32_t w_first = (uint32_t)__builtin_amdgcn_readlane((int)q, 0) & 0xFFu;
+        for (uint32_t c = 0; c < cnt; c += 4u * kWave) {
+            const uint32_t j0 = c + 4u * lane;
+            const uint32_t qn = c + 4u * kWave <= cnt ? chain_ent4(E, F, j0 + 4u * kWave, b_merge, shift) : 0u;   // (entry cnt included)
+            uint32_t e4 = (uint32_t)__shfl_down((int)(q & 0xFFu), 1, 64);
+            if (lane == 63u) e4 = (uint32_t)__builtin_amdgcn_readlane((int)qn, 0) & 0xFFu;
+            const uint32_t e[5] = {q & 0xFFu, (q >> 8) & 0xFFu, (q >> 16) & 0xFFu, q >> 24, e4};
+            uint32_t len[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = j0 + (uint32_t)k < cnt;
+                len[k] = in ? header_len(e[k + 1], e[k]) + (uint32_t)kBlock * e[k + 1] : 0u;
+                bad = bad || (in && e[k + 1] > max_w);
+                sum += len[k];
+            }
+            const uint32_t incl = wave_inclusive_scan(sum);
+            uint32_t at = pos + incl - sum;
+            const uint32_t packed = e[1] | (e[2] << 8) | (e[3] << 16) | (e[4] << 24);
+            if (j0 + 4u <= cnt) __builtin_memcpy(wf + j0, &packed, 4);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (j0 + (uint32_t)k < cnt) wf[j0 + (uint32_t)k] = (uint8_t)e[k + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (j0 + (uint32_t)k < cnt && ((d.b0 + j0 + (uint32_t)k) & (uint32_t)(kTileBlocks - 1)) == 0u)
+                    tf[(d.b0 + j0 + (uint32_t)k) / (uint32_t)kTileBlocks] = at;
+                at += len[k];
+            }
+            pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            // the width of the part's last block (entry cnt): whichever lane holds it in this step
+            const uint32_t rel = cnt - c;                                    // entry cnt = e[rel - 4 * lane] of lane (rel - 1) / 4 ... or lane rel / 4's e[0]
+            if (rel <= 4u * kWave) {
+                const uint32_t ln = (rel - 1u) / 4u, kk = rel - 4u * ln;     // 1 .. 4
+                const uint32_t v = kk == 1u ? e[1] : kk == 2u ? e[2] : kk == 3u ? e[3] : e[4];
+                w_last = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)ln);
+            }
+            q = qn;
+        }
+        done = !__ballot(bad) && pos == d.pos1 && w_last == d.w1 && w_first == d.w0;
+        // (not what the walk arrived at: e.g. a stream whose writer spelled out a width that repeats -- the walk below reads
+        // the headers themselves)
+    }
+    if (!done) {
+        if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+        PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
+        uint32_t pos = d.pos0, w = d.w0;
+        bool ok = f.ok && d.pos0 < f.limit && chain_walk_abs(f.W, s_chunk, pos, w, cnt, at_end, nb_last, f.limit, max_w, wf, tf, d.b0);
+        if (ok) ok = at_end ? (pos <= f.limit && 1u + (uint64_t)pos / 8u == fe - fo) : (pos == d.pos1 && w == d.w1);   // S_f (Terse.hpp:547) / the next part's start
+        // Not the frame's chain after all (a table k_chain_resolve put together from walks that agreed by chance, or a damaged
+        // stream): the frame is listed -- once -- for the position-parallel walk, which writes its whole index again and reports
+        // what is corrupt.
+        if (!ok && lane == 0 && (atomicOr(&parts[(uint64_t)frame * P].pad, 0x80000000u) & 0x80000000u) == 0u) {
+            list[1u + atomicAdd(&list[0], 1u)] = frame;
+            atomicAdd(status + 2, 1u);
+        }
+    }
+}
+
+// Fills a.widths / a.tile_off for every frame that works out and lists the others in a.defer.
+hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
+    const uint32_t P = a.parts_per_frame;
+    if (P < 4u || !a.parts || !a.part_ws || !a.defer) return hipErrorInvalidValue;
+    const ChainWs l = chain_ws_layout(a.geom, a.n_frames, P);
+    char* ws = static_cast<char*>(a.part_ws);
+    PartState* states = reinterpret_cast<PartState*>(ws + l.states);
+    PartWalk* walks = reinterpret_cast<PartWalk*>(ws + l.walks);
+    ChainFix* fixes = reinterpret_cast<ChainFix*>(ws + l.fixes);
+    PartCk* cks = reinterpret_cast<PartCk*>(ws + l.cks);
+    uint8_t* ents = reinterpret_cast<uint8_t*>(ws + l.ents);
+    uint8_t* fixents = reinterpret_cast<uint8_t*>(ws + l.fixents);
+    const uint32_t cap = chain_ent_cap(a.geom.n_blocks, P);
+    const dim3 links(a.n_frames * (P - 1u));
+    hipLaunchKernelGGL(k_chain_guess, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, states);
+    hipLaunchKernelGGL(k_chain_walk, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, cap,
+                       static_cast<const PartState*>(states), walks, cks, ents, a.status);
+    hipLaunchKernelGGL(k_chain_repair, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
+                       static_cast<const PartState*>(states), static_cast<const PartWalk*>(walks), static_cast<const PartCk*>(cks), fixes, fixents, cap);
+    hipLaunchKernelGGL(k_chain_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartWalk*>(walks),
+                       static_cast<const ChainFix*>(fixes), a.geom, P, a.parts, a.defer, a.status);
+    hipLaunchKernelGGL(k_chain_index, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
+                       max_w, P, cap, a.parts, ents, static_cast<const ChainFix*>(fixes), static_cast<const uint8_t*>(fixents), a.widths,
+                       a.tile_off, a.defer, a.status);
     return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@
 #include "encode_kernels.hpp"
 #include "profile.hpp"
 #include "unpack_tile.hpp"
+#include "walk_lds.hpp"
 #include <stdlib.h>
 
 namespace trpx {
@@ -793,15 +794,16 @@ __device__ __forceinline__ bool seg_listed_frame(const uint32_t* __restrict__ li
 }
 
 // ---- several wavefronts per frame (large frames): rounds / resolve / write are separate launches -------------------------
-__global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                     uint32_t K, uint32_t first, SegWs ws, uint8_t* __restrict__ widths,
-                                                     const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
-    __shared__ uint32_t win[kWave * kSegRow];
+// (item = slot * K + k: wavefront k of the frame in slot `slot` of the launch -- see seg_listed_frame)
+__device__ __forceinline__ void seg_round_item(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                               const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
+                                               uint32_t K, uint32_t first, const SegWs& ws, uint8_t* __restrict__ widths,
+                                               const uint32_t* __restrict__ list, uint32_t* __restrict__ status, uint32_t item,
+                                               uint32_t* __restrict__ win) {
     uint64_t frame;
     bool run_guess;
-    if (!seg_listed_frame(list, blockIdx.x / K, frame, run_guess)) return;
-    const uint32_t k = blockIdx.x % K;
+    if (!seg_listed_frame(list, item / K, frame, run_guess)) return;
+    const uint32_t k = item % K;
     SegCtx c;
     if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave, status)) {
         if (threadIdx.x == 0 && k == 0) atomicMax(&status[0], 5u);
@@ -818,24 +820,31 @@ __global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__
     seg_fixpoint(c, win, k, jl, first != 0u, k == 0u || first == 0u, first ? 4 : 12, seg_state(ws, frame, K), run_guess);
 #ifdef TRPX_SEG_STAMPS
     if (first && threadIdx.x == 0) {                            // tools/c4_time.py (SEG_PER_WAVE=1): status block of 16 + 8 * waves words
-        uint32_t* o = status + 16 + 8 * blockIdx.x;
+        uint32_t* o = status + 16 + 8 * item;
         o[0] = (uint32_t)t_a; o[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_a);
         o[3] = (uint32_t)c.clk_wait[0]; o[4] = (uint32_t)c.clk_step[0]; o[5] = (uint32_t)c.clk_guess; o[6] = c.clk_rounds;
     }
 #endif
 }
 
+__global__ __launch_bounds__(kWave) void k_seg_round(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                     uint32_t K, uint32_t first, SegWs ws, uint8_t* __restrict__ widths,
+                                                     const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    __shared__ uint32_t win[kWave * kSegRow];
+    seg_round_item(terse, terse_bytes, frame_offsets, g, max_w, K, first, ws, widths, list, status, blockIdx.x, win);
+}
+
 // One wavefront per frame: closes the links the rounds left open -- between the frame's waves and inside them --
 // serially, wave by wave (each re-run starts from a verified state), and turns the block counts into block bases.
 // A frame with too many open waves is left to the serial walk (fallback flag).
-__global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                       const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                       uint32_t K, SegWs ws, const uint32_t* __restrict__ list,
-                                                       uint32_t* __restrict__ status) {
-    __shared__ uint32_t win[kWave * kSegRow];
+__device__ __forceinline__ void seg_resolve_item(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                 const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
+                                                 uint32_t K, const SegWs& ws, const uint32_t* __restrict__ list,
+                                                 uint32_t* __restrict__ status, uint32_t slot, uint32_t* __restrict__ win) {
     uint64_t frame;
     bool run_guess;
-    if (!seg_listed_frame(list, blockIdx.x, frame, run_guess)) return;
+    if (!seg_listed_frame(list, slot, frame, run_guess)) return;
     const uint32_t lane = (uint32_t)lane_id();
     if (lane == 0) ws.fallback[frame] = 0u;
     SegCtx c;
@@ -876,16 +885,23 @@ __global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                     uint32_t K, SegWs ws, uint8_t* __restrict__ widths,
-                                                     uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ list,
-                                                     uint32_t* __restrict__ status) {
+__global__ __launch_bounds__(kWave) void k_seg_resolve(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                       const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                       uint32_t K, SegWs ws, const uint32_t* __restrict__ list,
+                                                       uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kWave * kSegRow];
+    seg_resolve_item(terse, terse_bytes, frame_offsets, g, max_w, K, ws, list, status, blockIdx.x, win);
+}
+
+__device__ __forceinline__ void seg_write_item(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                               const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
+                                               uint32_t K, const SegWs& ws, uint8_t* __restrict__ widths,
+                                               uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ list,
+                                               uint32_t* __restrict__ status, uint32_t item, uint32_t* __restrict__ win) {
     uint64_t frame;
     bool run_guess;
-    if (!seg_listed_frame(list, blockIdx.x / K, frame, run_guess)) return;
-    const uint32_t k = blockIdx.x % K;
+    if (!seg_listed_frame(list, item / K, frame, run_guess)) return;
+    const uint32_t k = item % K;
     const uint32_t lane = (uint32_t)lane_id();
     if (ws.fallback[frame]) return;                            // the serial walk does this frame
     SegCtx c;
@@ -899,6 +915,83 @@ __global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__
     const uint32_t base = st.wbase[k] + wave_inclusive_scan(cnt) - cnt;
     seg_write(c, win, k, jl, st.in[j], has_next ? st.in[j + 1u] : 0ull, has_next ? st.bnd[j + 1u] : 0xFFFFFFFFu, base,
               widths + frame * g.n_blocks, tile_off + frame * g.n_tiles, c.limit / 8u, status);
+}
+
+__global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                     uint32_t K, SegWs ws, uint8_t* __restrict__ widths,
+                                                     uint64_t* __restrict__ tile_off, const uint32_t* __restrict__ list,
+                                                     uint32_t* __restrict__ status) {
+    __shared__ uint32_t win[kWave * kSegRow];
+    seg_write_item(terse, terse_bytes, frame_offsets, g, max_w, K, ws, widths, tile_off, list, status, blockIdx.x, win);
+}
+
+// ---- the same six launches as ONE, for a list that is normally empty -------------------------------------------------------------
+// Behind the routes that handle large frames by themselves (decode_part.hip) the position-parallel walk is the fallback for the
+// frames they list -- normally none, and then launch_seg_multi's six launches are six empty grids of a wavefront per (frame,
+// segment group): 4.6 - 4.9 us each, 28 us = 7 - 14 % of such a decode.  k_seg_fallback is a small persistent grid instead:
+// every workgroup reads the list's count and leaves if it is zero (one launch: 4 us); otherwise the grid strides over the items
+// of each phase -- rounds x 3, resolve, write, the serial walk of frames that did not converge -- with a device-wide barrier
+// between them (a counter every workgroup adds to and waits for, the waits bounded like the encoder's look-back; all kSegFbGrid
+// workgroups are resident at once: 64 threads, 16.6 KB of LDS each).  Results are what the six launches produce.
+constexpr uint32_t kSegFbGrid = 1024;
+__device__ __forceinline__ bool seg_grid_barrier(uint64_t* __restrict__ ctr, uint32_t& epoch) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    ++epoch;
+    bool ok = true;
+    if (lane_id() == 0) {
+        __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t want = (uint64_t)epoch * gridDim.x;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { ok = false; break; }   // 1 s of the 100 MHz counter: a workgroup that never arrives
+        }
+    }
+    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    // (uniform loads of what other workgroups wrote go through the scalar cache)
+    return ok;
+}
+__global__ __launch_bounds__(kWave) void k_seg_fallback(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                        const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                        uint32_t K, SegWs ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                        const uint32_t* __restrict__ list, uint64_t* __restrict__ barrier,
+                                                        uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_lds[kWalkChunkDw + 4 > kWave * kSegRow ? kWalkChunkDw + 4 : kWave * kSegRow];
+    const uint32_t count = __hip_atomic_load(&list[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count == 0u) return;                                                  // the normal case
+    const uint32_t items = count * K;
+    uint32_t epoch = 0;
+    bool ok = true;
+    for (uint32_t phase = 0; phase < 3u && ok; ++phase) {
+        for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+            seg_round_item(terse, terse_bytes, frame_offsets, g, max_w, K, phase == 0u ? 1u : 0u, ws, widths, list, status, it, s_lds);
+            __builtin_amdgcn_wave_barrier();
+        }
+        ok = seg_grid_barrier(barrier, epoch);
+    }
+    if (ok) {
+        for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+            seg_resolve_item(terse, terse_bytes, frame_offsets, g, max_w, K, ws, list, status, it, s_lds);
+            __builtin_amdgcn_wave_barrier();
+        }
+        ok = seg_grid_barrier(barrier, epoch);
+    }
+    if (ok) {
+        for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+            seg_write_item(terse, terse_bytes, frame_offsets, g, max_w, K, ws, widths, tile_off, list, status, it, s_lds);
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {         // (the flags are the resolve phase's: no barrier needed in between)
+            const uint64_t frame = list[1u + it] & 0x7FFFFFFFu;
+            if (__hip_atomic_load(&ws.fallback[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                walk_lds_frame(terse, terse_bytes, frame_offsets, g, max_w, widths, tile_off, frame, s_lds, status);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!ok && threadIdx.x == 0) atomicMax(&status[0], 7u);                   // TRPX_ERR_TIMEOUT: a device-wide barrier gave up
 }
 
 // Segments per frame: a multiple of 64.  Frames of up to 32 K blocks (512 x 512: 21 846) are one wavefront -- rounds, prefix
@@ -926,6 +1019,14 @@ hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint3
 // Several wavefronts per frame: every frame of the stack (list == nullptr) or the frames of a list.
 static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t K, const uint32_t* list, hipStream_t st) {
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, K);
+    if (list && a.defer && list == a.defer) {          // a list that is normally empty: one launch (k_seg_fallback)
+        // the barrier counter: the last word of the statistics slots in front of the list (codec_common.hpp), cleared with them by
+        // the call's first launch and used by nothing else
+        uint64_t* barrier = reinterpret_cast<uint64_t*>(a.defer) - 1;
+        hipLaunchKernelGGL(k_seg_fallback, dim3(kSegFbGrid), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
+                           max_w, K, ws, a.widths, a.tile_off, list, barrier, a.status);
+        return hipGetLastError();
+    }
     const dim3 grid((uint32_t)((size_t)a.n_frames * K));
     hipLaunchKernelGGL(k_seg_round, grid, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
                        K, 1u, ws, a.widths, list, a.status);

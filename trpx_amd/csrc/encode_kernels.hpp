@@ -54,12 +54,20 @@ struct DecodeArgs {
     // frames of more than kPartMaxBlocks blocks on the per-frame route: the part table and the scratch of its construction
     PartDesc*       parts = nullptr;           // n_frames * parts_per_frame entries
     uint32_t        parts_per_frame = 1;
-    void*           part_ws = nullptr;         // part_workspace_bytes()
+    void*           part_ws = nullptr;         // part_workspace_bytes() / chain_workspace_bytes()
+    bool            chain = false;             // large frames by the index route (decode_part.hip: one walk -> the decode index -> extraction with the widths given); parts / parts_per_frame / part_ws are that route's
 };
 uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames);
 size_t part_workspace_bytes(const FrameGeom& g, size_t n_frames);
 // decode_part.hip: fills a.parts for every frame; frames whose parts cannot be established are listed in a.defer (whole frames)
 hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
+// decode_part.hip, the index route: a.widths / a.tile_off of every large frame from ONE walk of many short parts; frames where
+// that does not work out are listed in a.defer (the position-parallel walk writes their index: launch_seg_listed)
+uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames);
+size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames);
+hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
+// decode_fast.hip: the tiled extraction of every frame with a.widths / a.tile_off given (no status clear, no profiler marks)
+hipError_t launch_unpack_tiles(int dtype, const DecodeArgs& a, hipStream_t st);
 
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
 // any block size (encode.hip, correct-first kernels): geom.block != 12
@@ -77,6 +85,7 @@ hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, h
 // one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const uint32_t* list, hipStream_t st);   // widths / group offsets given
+hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st);                         // the same over units of 6144 blocks of large frames
 hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_status, hipStream_t st);   // the index by the per-frame walker (needs a.defer, a.seg_ws)
 hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st);                       // decode_seg.hip: index of the frames listed in a.defer
 hipError_t launch_seg_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, hipStream_t st);   // decode_seg.hip: index from group states (frames < 2^32 bits)
