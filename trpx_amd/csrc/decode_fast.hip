@@ -52,12 +52,14 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 4 : 5) void k_unpack_til
                                                               uint32_t tiles_per_frame,
                                                               const uint8_t* __restrict__ widths,
                                                               const uint64_t* __restrict__ tile_off,
-                                                              T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+                                                              T* __restrict__ pixels_out, uint32_t* __restrict__ status,
+                                                              const uint32_t* __restrict__ frame_mode) {
     __shared__ uint32_t s_image[unpack_image_dwords<T>()];
     __shared__ uint32_t s_wtot[unpack_sub_tiles<T>() * 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[unpack_stage_dwords<T>()];
     if (status[0] != 0) return;                             // corrupt chain: produce nothing
     const uint64_t tile = blockIdx.x;
+    if (frame_mode && frame_mode[tile / tiles_per_frame] == 0u) return;   // (large frames: this one is extracted part by part, decode_part.hip)
     unpack_tile<T>(terse, terse_bytes, frame_offsets, g, (uint32_t)(tile / tiles_per_frame), (uint32_t)(tile % tiles_per_frame),
                    widths, tile_off, pixels_out, status, s_image, s_wtot, s_stage);
 }
@@ -168,27 +170,27 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, boo
     }
     hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
                        (uint64_t)a.terse_bytes, a.frame_offsets, g, tpf, a.widths, a.tile_off,
-                       static_cast<T*>(a.pixels_out), a.status);
+                       static_cast<T*>(a.pixels_out), a.status, static_cast<const uint32_t*>(nullptr));
     prof.mark(st);
     return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t launch_unpack_tiles_t(const DecodeArgs& a, hipStream_t st) {
+static hipError_t launch_unpack_tiles_t(const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
     constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
     const uint32_t tpf = (a.geom.n_blocks + tb - 1) / tb;
     hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
-                       (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, tpf, a.widths, a.tile_off, static_cast<T*>(a.pixels_out), a.status);
+                       (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, tpf, a.widths, a.tile_off, static_cast<T*>(a.pixels_out), a.status, frame_mode);
     return hipGetLastError();
 }
-hipError_t launch_unpack_tiles(int dtype, const DecodeArgs& a, hipStream_t st) {
+hipError_t launch_unpack_tiles(int dtype, const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
     switch (dtype) {
-    case 0: return launch_unpack_tiles_t<uint8_t>(a, st);
-    case 1: return launch_unpack_tiles_t<int8_t>(a, st);
-    case 2: return launch_unpack_tiles_t<uint16_t>(a, st);
-    case 3: return launch_unpack_tiles_t<int16_t>(a, st);
-    case 4: return launch_unpack_tiles_t<uint32_t>(a, st);
-    case 5: return launch_unpack_tiles_t<int32_t>(a, st);
+    case 0: return launch_unpack_tiles_t<uint8_t>(a, st, frame_mode);
+    case 1: return launch_unpack_tiles_t<int8_t>(a, st, frame_mode);
+    case 2: return launch_unpack_tiles_t<uint16_t>(a, st, frame_mode);
+    case 3: return launch_unpack_tiles_t<int16_t>(a, st, frame_mode);
+    case 4: return launch_unpack_tiles_t<uint32_t>(a, st, frame_mode);
+    case 5: return launch_unpack_tiles_t<int32_t>(a, st, frame_mode);
     }
     return hipErrorInvalidValue;
 }

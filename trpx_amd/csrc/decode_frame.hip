@@ -735,8 +735,9 @@ template <typename T>
 __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_parts(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                T* __restrict__ pixels_out, uint32_t* __restrict__ status,
-                                                               const PartDesc* __restrict__ parts) {
+                                                               const PartDesc* __restrict__ parts, const uint32_t* __restrict__ frame_mode) {
     if (status[0] != 0u) return;
+    if (frame_mode && frame_mode[parts[blockIdx.x].frame] != 0u) return;   // (index route: this frame is extracted through its decode index)
     decode_frame_body<T, 0, true, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, blockIdx.x, nullptr, nullptr, parts);
 }
 
@@ -761,29 +762,31 @@ template <typename T>
 __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decode_units_indexed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                                const uint64_t* __restrict__ frame_offsets, FrameGeom g,
                                                                const uint8_t* __restrict__ widths, const uint64_t* __restrict__ group_off,
-                                                               uint32_t unit_blocks, T* __restrict__ pixels_out, uint32_t* __restrict__ status) {
+                                                               uint32_t unit_blocks, T* __restrict__ pixels_out, uint32_t* __restrict__ status,
+                                                               const uint32_t* __restrict__ frame_mode) {
     if (status[0] != 0u) return;
+    if (frame_mode && frame_mode[blockIdx.x / ((g.n_blocks + unit_blocks - 1u) / unit_blocks)] == 0u) return;   // (extracted part by part)
     decode_frame_body<T, 1, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, blockIdx.x, widths, group_off,
                                   reinterpret_cast<const PartDesc*>((uintptr_t)unit_blocks));
 }
 template <typename T>
-static hipError_t launch_decode_units_indexed_t(const DecodeArgs& a, hipStream_t st) {
+static hipError_t launch_decode_units_indexed_t(const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
     constexpr uint32_t unit_blocks = 8u * FrameCfg<T>::kStepBlocks;          // 6144 blocks: eight super-steps, 24 groups of 256
     static_assert(unit_blocks % kTileBlocks == 0, "units start on index groups");
     const uint32_t upf = (a.geom.n_blocks + unit_blocks - 1u) / unit_blocks;
     hipLaunchKernelGGL((k_decode_units_indexed<T>), dim3(a.n_frames * upf), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), unit_blocks,
-                       static_cast<T*>(a.pixels_out), a.status);
+                       static_cast<T*>(a.pixels_out), a.status, frame_mode);
     return hipGetLastError();
 }
-hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st) {
+hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
     switch (dtype) {
-    case 0: return launch_decode_units_indexed_t<uint8_t>(a, st);
-    case 1: return launch_decode_units_indexed_t<int8_t>(a, st);
-    case 2: return launch_decode_units_indexed_t<uint16_t>(a, st);
-    case 3: return launch_decode_units_indexed_t<int16_t>(a, st);
-    case 4: return launch_decode_units_indexed_t<uint32_t>(a, st);
-    case 5: return launch_decode_units_indexed_t<int32_t>(a, st);
+    case 0: return launch_decode_units_indexed_t<uint8_t>(a, st, frame_mode);
+    case 1: return launch_decode_units_indexed_t<int8_t>(a, st, frame_mode);
+    case 2: return launch_decode_units_indexed_t<uint16_t>(a, st, frame_mode);
+    case 3: return launch_decode_units_indexed_t<int16_t>(a, st, frame_mode);
+    case 4: return launch_decode_units_indexed_t<uint32_t>(a, st, frame_mode);
+    case 5: return launch_decode_units_indexed_t<int32_t>(a, st, frame_mode);
     }
     return hipErrorInvalidValue;
 }
@@ -851,7 +854,9 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
         if (!defer) return hipErrorInvalidValue;
         constexpr int dt = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0)
                            : PixelTraits<T>::bits == 16 ? (PixelTraits<T>::is_signed ? 3 : 2) : (PixelTraits<T>::is_signed ? 5 : 4);
-        hipError_t e = launch_build_index_chain(a, (uint32_t)PixelTraits<T>::bits, st);
+        constexpr bool narrow = sizeof(T) < 4;
+        const uint32_t* frame_mode = nullptr;
+        hipError_t e = launch_build_index_chain(a, (uint32_t)PixelTraits<T>::bits, narrow, &frame_mode, st);
         if (e != hipSuccess) return e;
         prof.mark(st);
         e = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
@@ -863,9 +868,13 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
 #else
         const bool tiles = sizeof(T) == 4 || a.geom.n_blocks < (1u << 18);
 #endif
-        e = tiles ? launch_unpack_tiles(dt, a, st) : launch_decode_units_indexed(dt, a, st);
+        e = tiles ? launch_unpack_tiles(dt, a, st, narrow ? frame_mode : nullptr) : launch_decode_units_indexed(dt, a, st, narrow ? frame_mode : nullptr);
+        if (e != hipSuccess) return e;
+        if constexpr (narrow)                                                 // frames with few explicit headers: part by part, walker + extraction fused
+            hipLaunchKernelGGL((k_decode_parts<T>), dim3(a.n_frames * a.parts_per_frame), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                               a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status, static_cast<const PartDesc*>(a.parts), frame_mode);
         prof.mark(st);
-        return e;
+        return hipGetLastError();
     } else if (a.parts && a.parts_per_frame > 1u) {
         // Large frames: cut into parts first (decode_part.hip: a walk-only pass from guessed states inside runs of equal widths,
         // verified link by link); frames whose parts cannot be established -- no runs to start from: header-dense data -- are
@@ -874,7 +883,8 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
         const hipError_t e = launch_build_parts(a, (uint32_t)PixelTraits<T>::bits, st);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_decode_parts<T>), dim3(a.n_frames * a.parts_per_frame), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                           a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status, static_cast<const PartDesc*>(a.parts));
+                           a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), a.status, static_cast<const PartDesc*>(a.parts),
+                           static_cast<const uint32_t*>(nullptr));
     } else if ((a.geom.n_values * sizeof(T)) % 128u == 0u && (uintptr_t)a.pixels_out % 128u == 0u)   // every frame starts a cache line
         hipLaunchKernelGGL((k_decode_frames<T, false>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                            a.frame_offsets, a.geom, static_cast<T*>(a.pixels_out), defer, a.status);

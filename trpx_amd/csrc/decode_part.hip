@@ -60,8 +60,8 @@ struct PartWalk {                              // what k_part_walk leaves per (f
     uint32_t cnt;                              // blocks started in [S_p, T_p)
     uint32_t flags;                            // 1: the chain left the frame / held an illegal width; 2: too dense for the serial walker
     uint32_t n_ck;                             // checkpoints left behind
-    uint32_t s_pos, s_w;                       // (index route) the state the counting walk started in: the guess, or where the warm-up chain crossed the cut
-    uint32_t pad;
+    uint32_t s_pos, s_w;                       // (index route) the state the counting walk started in: the guess, or behind the last illegal width
+    uint32_t pad;                              // (index route) explicit headers among the blocks counted
 };
 struct PartFix {                               // what k_part_repair leaves per (frame, part 1 <= p < P - 1)
     uint32_t state;                            // 0: link closed, nothing done; 1: merged into the part's walk; 2: walked to T_p on its own; 3: failed
@@ -376,7 +376,8 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
                                           uint32_t limit, uint32_t max_w, uint32_t& count, bool& bad, bool& dense,
                                           PartCk* __restrict__ ck, uint32_t ck_every, uint32_t& n_ck, bool tolerant,
                                           uint32_t ck_cap = kPartCk, bool stop_dense = true, uint8_t* __restrict__ ent = nullptr,
-                                          uint32_t ent_cap = 1u, bool abort_illegal = false, uint32_t prio_span = 0u) {
+                                          uint32_t ent_cap = 1u, bool abort_illegal = false, uint32_t prio_span = 0u,
+                                          uint32_t* __restrict__ exp_out = nullptr) {
     const uint32_t lane = (uint32_t)lane_id();
     uint32_t b = 0, n_exp = 0, b_ref = 0, exp_ref = 0;
     uint32_t ck_next = ck ? pos + ck_every : 0xFFFFFFFFu;
@@ -567,6 +568,7 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
         if (pos > limit) { bad = true; break; }
     }
     count = b;
+    if (exp_out) *exp_out = n_exp;                                            // explicit headers among the blocks counted
     if constexpr (STORE) {
         if (lane == 0) ent[b < capm1 ? b : capm1] = (uint8_t)w_prev;
     }
@@ -926,7 +928,7 @@ struct ChainFix {                              // what k_chain_repair leaves per
     uint32_t n_fix;                            // entries the repair left for its blocks [0, b_merge] (0: they did not fit)
     uint32_t pad;
 };
-struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, total; };
+struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, total; };
 static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     ChainWs w;
     w.states = 0;
@@ -935,7 +937,8 @@ static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     w.cks = align_up(w.fixes + n_frames * P * sizeof(ChainFix), 256);
     w.ents = align_up(w.cks + n_frames * P * kChainCk * sizeof(PartCk), 256);
     w.fixents = align_up(w.ents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);
-    w.total = align_up(w.fixents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);   // (a repair's entries: as many as a walk's)
+    w.modes = align_up(w.fixents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);   // (a repair's entries: as many as a walk's)
+    w.total = align_up(w.modes + 4 * n_frames, 256);
     return w;
 }
 size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames) {
@@ -1002,6 +1005,7 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
     if (f.ok && t.pos > s.pos && t.pos < f.limit) {
         uint32_t pos = s.pos, w = s.w & ~kPartFlags, cnt = 0, n_ck = 0;
         bool bad = false, dense = false, stopped = false;
+        uint32_t n_exp = 0;
         const uint32_t X = pos;
         // (how long a walk that reads illegal widths keeps starting again: for ever where the cut found no runs at all -- header-dense
         // data: false chains merge within a few K bits, and a stopped part costs its repair a whole part's walk, the repair launch's
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
             const uint32_t every = span / (kChainCk - 8u) > 4096u ? span / (kChainCk - 8u) : 4096u;
             dense = false;
             part_walk<true>(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cnt, bad, dense, cks + slot * kChainCk, every, n_ck, p != 0u,
-                            kChainCk, false, ents + slot * ent_cap, ent_cap, p != 0u, t.pos - X);
+                            kChainCk, false, ents + slot * ent_cap, ent_cap, p != 0u, t.pos - X, &n_exp);
             if (!dense || bad) break;
             if (pos >= t.pos || pos - X >= patience) {
                 stopped = true;
@@ -1042,7 +1046,7 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
             }
             w = 0u;                                                           // (pos: behind the illegal header)
         }
-        r.o_pos = pos; r.o_w = w; r.cnt = cnt; r.n_ck = n_ck;
+        r.o_pos = pos; r.o_w = w; r.cnt = cnt; r.n_ck = n_ck; r.pad = n_exp;
         r.flags = (bad ? 1u : 0u) | (cnt + 1u > ent_cap - 1u ? 8u : 0u) | (stopped ? 16u : 0u);   // 8: more blocks than entries; 16: stopped on a false chain
     }
     if (lane == 0) walks[slot] = r;
@@ -1151,15 +1155,20 @@ __global__ __launch_bounds__(kWave) void k_chain_repair(const uint8_t* __restric
 }
 
 // list[0] = count, list[1 + i] = frame (bit 31 clear: the position-parallel walk may look for runs).
+// mode[frame]: how the frame's pixels are extracted -- 1: through the decode index (k_chain_index, then the kernels that take the
+// widths as given); 0: part by part by the per-frame decoder's walker + extraction waves (k_decode_parts on this table: a second
+// walk, but one that hides under the extraction where explicit headers are rare -- 200 x (1030 x 1065) u16 synth-v1: 106 us
+// against k_chain_index 24 + k_unpack_tiles 122; where they are frequent the walker is that kernel's bound: Poisson(3) counts
+// 200 against 25 + 131).  `narrow` (8 / 16-bit pixels): by the frame's explicit headers per block; 32-bit pixels: always 1.
 __global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restrict__ walks, const ChainFix* __restrict__ fixes, FrameGeom g,
-                                                         uint32_t P, PartDesc* __restrict__ parts, uint32_t* __restrict__ list,
-                                                         uint32_t* __restrict__ status) {
+                                                         uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
+                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     const uint32_t frame = blockIdx.x, lane = (uint32_t)lane_id();
     const PartWalk* __restrict__ wf = walks + (uint64_t)frame * P;
     const ChainFix* __restrict__ xf = fixes + (uint64_t)frame * P;
     PartDesc* __restrict__ pf = parts + (uint64_t)frame * P;
     bool ok = true;
-    uint32_t running = 0;
+    uint32_t running = 0, n_explicit = 0;
     for (uint32_t base = 0; base < P - 1u; base += kWave) {
         const uint32_t p = base + lane;
         const bool valid = p < P - 1u;
@@ -1206,6 +1215,7 @@ __global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restr
             if (lane == 0) { atomicAdd(status + 4, n4); atomicAdd(status + 5, n5); atomicAdd(status + 6, n6); atomicAdd(status + 7, n7); }
         }
 #endif
+        n_explicit += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(valid ? r.pad : 0u), 63);
         const uint32_t c = valid && good ? cnt : 0u;
         const uint32_t inc = wave_inclusive_scan(c);
         if (valid && good) {
@@ -1223,6 +1233,7 @@ __global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restr
         if (tot >= g.n_blocks - running) ok = false;                          // (the last part holds at least the frame's last block)
         running += ok ? tot : 0u;
     }
+    if (lane == 0) mode[frame] = !narrow || !ok || 12u * n_explicit > running ? 1u : 0u;   // (a listed frame's index comes from the other route)
     if (!ok) {
 #ifdef TRPX_PART_STATS
         if (frame < 3u && lane == 0) printf("resolve: frame %u not ok, running %u of %u blocks, P %u\n", frame, running, g.n_blocks, P);
@@ -1313,11 +1324,11 @@ __global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict
                                                        uint32_t ent_cap, PartDesc* __restrict__ parts, uint8_t* __restrict__ ents,
                                                        const ChainFix* __restrict__ fixes, const uint8_t* __restrict__ fixents,
                                                        uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
-                                                       uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+                                                       uint32_t* __restrict__ mode, uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
     const uint32_t lane = (uint32_t)lane_id();
     const PartDesc d = parts[blockIdx.x];
-    if (d.b1 <= d.b0) return;                                                 // the frame took another route
+    if (d.b1 <= d.b0 || mode[d.frame] == 0u) return;                          // the frame took another route / is extracted part by part
     const uint32_t frame = d.frame, cnt = d.b1 - d.b0;
     const bool at_end = d.b1 == g.n_blocks;
     const uint32_t nb_last = (uint32_t)(g.n_values - (uint64_t)(g.n_blocks - 1) * kBlock);
@@ -1414,7 +1425,7 @@ __global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict
 }
 
 // Fills a.widths / a.tile_off for every frame that works out and lists the others in a.defer.
-hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
+hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool narrow, const uint32_t** frame_mode, hipStream_t st) {
     const uint32_t P = a.parts_per_frame;
     if (P < 4u || !a.parts || !a.part_ws || !a.defer) return hipErrorInvalidValue;
     const ChainWs l = chain_ws_layout(a.geom, a.n_frames, P);
@@ -1425,6 +1436,7 @@ hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, hipStre
     PartCk* cks = reinterpret_cast<PartCk*>(ws + l.cks);
     uint8_t* ents = reinterpret_cast<uint8_t*>(ws + l.ents);
     uint8_t* fixents = reinterpret_cast<uint8_t*>(ws + l.fixents);
+    uint32_t* modes = reinterpret_cast<uint32_t*>(ws + l.modes);
     const uint32_t cap = chain_ent_cap(a.geom.n_blocks, P);
     const dim3 links(a.n_frames * (P - 1u));
     hipLaunchKernelGGL(k_chain_guess, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, states);
@@ -1433,10 +1445,11 @@ hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, hipStre
     hipLaunchKernelGGL(k_chain_repair, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
                        static_cast<const PartState*>(states), static_cast<const PartWalk*>(walks), static_cast<const PartCk*>(cks), fixes, fixents, cap);
     hipLaunchKernelGGL(k_chain_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartWalk*>(walks),
-                       static_cast<const ChainFix*>(fixes), a.geom, P, a.parts, a.defer, a.status);
+                       static_cast<const ChainFix*>(fixes), a.geom, P, narrow ? 1u : 0u, a.parts, modes, a.defer, a.status);
     hipLaunchKernelGGL(k_chain_index, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
                        max_w, P, cap, a.parts, ents, static_cast<const ChainFix*>(fixes), static_cast<const uint8_t*>(fixents), a.widths,
-                       a.tile_off, a.defer, a.status);
+                       a.tile_off, modes, a.defer, a.status);
+    *frame_mode = modes;
     return hipGetLastError();
 }
 

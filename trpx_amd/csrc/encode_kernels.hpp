@@ -65,9 +65,11 @@ hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t s
 // that does not work out are listed in a.defer (the position-parallel walk writes their index: launch_seg_listed)
 uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames);
 size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames);
-hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
+// narrow: 8 / 16-bit pixels -- frames with few explicit headers are left to k_decode_parts on a.parts (*frame_mode: per frame, 1 = the
+// index was written, 0 = extract part by part)
+hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool narrow, const uint32_t** frame_mode, hipStream_t st);
 // decode_fast.hip: the tiled extraction of every frame with a.widths / a.tile_off given (no status clear, no profiler marks)
-hipError_t launch_unpack_tiles(int dtype, const DecodeArgs& a, hipStream_t st);
+hipError_t launch_unpack_tiles(int dtype, const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode = nullptr);   // frame_mode: only frames with mode 1
 
 hipError_t launch_encode(int dtype, const EncodeArgs& a, hipStream_t st);
 // any block size (encode.hip, correct-first kernels): geom.block != 12
@@ -85,7 +87,7 @@ hipError_t launch_decode_fast(int dtype, const DecodeArgs& a, bool have_index, h
 // one workgroup per frame, walk and extraction fused through LDS (decode_frame.hip): many small frames
 hipError_t launch_decode_frames(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const uint32_t* list, hipStream_t st);   // widths / group offsets given
-hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st);                         // the same over units of 6144 blocks of large frames
+hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode = nullptr);                         // the same over units of 6144 blocks of large frames
 hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_status, hipStream_t st);   // the index by the per-frame walker (needs a.defer, a.seg_ws)
 hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st);                       // decode_seg.hip: index of the frames listed in a.defer
 hipError_t launch_seg_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, hipStream_t st);   // decode_seg.hip: index from group states (frames < 2^32 bits)
