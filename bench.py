@@ -32,9 +32,16 @@ N_VALUES = 512 * 512
 FRAMES_PER_GPU = 2000
 ENC_STAGES_TWOPASS = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
 ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
-DEC_STAGES = ["walk", "unpack"]        # tiled decode (two kernels)
 PROFILE_TAG = "r04"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
 DEC_STAGES_FRAMES = ["decode_frames", "deferred_frames"]  # one workgroup per frame (walk + extraction fused) + the frames it defers
+# frames of more than 32 K blocks (decode_part.hip, the index route): the one walk of short parts up to the part table / decode index
+# (k_chain_guess, k_chain_walk, k_chain_repair, k_chain_resolve, k_chain_index), then the other route's launch for listed frames
+# (k_seg_fallback, normally empty) + the extraction (k_unpack_tiles / k_decode_units_indexed / k_decode_parts)
+DEC_STAGES_LARGE = ["chain_walk_to_index", "fallback_and_extract"]
+
+
+def dec_stage_names(n_values):
+    return DEC_STAGES_LARGE if (n_values + 11) // 12 > 32768 else DEC_STAGES_FRAMES
 
 
 def kernel_sources_sha16() -> str:
@@ -217,14 +224,17 @@ def main():
         # the C-ABI gather on its own RCCL communicator; if ANY rank cannot set it up (agreed on collectively, so that no rank
         # waits in a collective the others never enter), every rank takes the same exchange through torch.distributed instead
         try:
-            gather, ok = sharded.RcclSizeGather(frames, dev), 1
+            gather, ok = sharded.ShardedCodec(frames, N_VALUES, np.uint16, dev), 1
         except Exception as ex:
             print(f"bench.py rank {rank}: C-ABI RCCL gather unavailable ({ex!r})", file=sys.stderr)
             gather, ok = None, 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            gather_kind = "trpx_gather_frame_offsets (C ABI: pack kernel + ncclAllGather + scan kernel)"
+            # ONE C-ABI call per step and rank: trpx_encode_sharded = trpx_encode of the rank's frames + pack kernel + ncclAllGather +
+            # scan kernel, the gather on the second stream; the codec object owns the rank's stack, offsets and status
+            gather_kind = "trpx_encode_sharded (C ABI: trpx_encode + pack kernel + ncclAllGather + scan kernel in one call, the gather on a second stream)"
+            out, offs, st_e = gather.out, gather.local_offsets, gather.status
         else:
             if gather is not None:
                 gather.close()
@@ -234,13 +244,18 @@ def main():
             gather_kind = "torch.distributed all_gather_into_tensor (fallback)"
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
+    one_call = use_dist and isinstance(gather, sharded.ShardedCodec)
+
     def step():
-        enc = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
-        if use_dist:
-            cur = torch.cuda.current_stream()
-            comm_stream.wait_stream(cur)
-            with torch.cuda.stream(comm_stream):
-                gather(offs, st_e)
+        if one_call:
+            enc = gather.encode(px, gather_stream=comm_stream)
+        else:
+            enc = codec.encode(px, out=out, workspace=ws, frame_offsets=offs, status=st_e)
+            if use_dist:
+                cur = torch.cuda.current_stream()
+                comm_stream.wait_stream(cur)
+                with torch.cuda.stream(comm_stream):
+                    gather(offs, st_e)
         # decode straight from the device-resident stack (bounded by its worst-case capacity; the
         # frame offsets tell the kernels where every frame ends -- no host sync inside the step)
         codec.decode(out, offs, N_VALUES, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
@@ -273,10 +288,15 @@ def main():
     if rank == 0 and frames == FRAMES_PER_GPU:
         assert total_bytes == 203596114, "stack size differs from the reference's (SURVEY.md 8 row d)"
     if use_dist:                                             # what the step's gather computed: this rank's place in the global stack
-        goffs, gbase, gpb = gather(offs, st_e)
+        goffs, gbase, gpb = gather.encode(px) if one_call else gather(offs, st_e)
         torch.cuda.synchronize()
         assert int(goffs[rank * frames + frames] - goffs[rank * frames]) == total_bytes and int(gbase) == int(goffs[rank * frames])
         assert int(gpb) >= int(st_e[1].item())
+        if one_call:                                         # ... and the rank's frames expanded from the GLOBAL table (trpx_decode_sharded)
+            back.zero_()
+            _, sd = gather.decode(back)
+            torch.cuda.synchronize()
+            assert int(sd[0].item()) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16)), "trpx_decode_sharded differs"
 
     # ---- the encoded stack against the CPU oracle (a sample of what was just timed; rank 0) ----
     oracle_check = None
@@ -395,7 +415,7 @@ def main():
             t_p = timed(lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws_d), 5)
             assert int(s4[0].item()) == 0 and torch.equal(b4, px4)
             st4 = stages(lambda: codec.encode(px4, out=e4.data, frame_offsets=e4.frame_offsets, status=e4.status, workspace=ws),
-                         lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws_d), DEC_STAGES, 5)
+                         lambda: codec.decode(e4.data, e4.frame_offsets, n4, f4, np.int32, out=b4, status=s4, workspace=ws_d), dec_stage_names(n4), 5)
             alg4 = f4 * n4 * 4 + e4.total_bytes()
             c4 = {"workload": f"{f4} frames 4096x4096 int32 synth-v1 (bg -3..3 + sparse peaks < 2^24)",
                   "encode_fps": f4 / t_e * 1e3, "encode_pixel_GBps": f4 * n4 * 4 / t_e / 1e6,
@@ -460,7 +480,7 @@ def main():
             t_i = timed(lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, status=st_d, index=en_i.index))
             assert int(st_d[0].item()) == 0 and torch.equal(bk.view(torch.int16), pxl.view(torch.int16)), f"{what}: indexed decode differs"
             km = stages(lambda: codec.encode(pxl, out=out, workspace=ws, frame_offsets=fo, status=st_e),
-                        lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws_d, status=st_d), DEC_STAGES_FRAMES, 5)
+                        lambda: codec.decode(out, fo, nv, nf, np.uint16, out=bk, workspace=ws_d, status=st_d), dec_stage_names(nv), 5)
             pb = nf * nv * 2
             alg = pb + nbytes
             return {"workload": what, "frames": nf, "n_values": nv,

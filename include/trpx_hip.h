@@ -358,6 +358,26 @@ int trpx_gather_pack(const uint64_t* local_offsets, size_t n_local, size_t n_slo
                      void* stream);
 int trpx_gather_scan(const uint64_t* all_messages, int world, size_t n_slot, uint64_t* global_offsets, uint32_t* prolix_bits,
                      uint64_t* rank_base, void* stream);
+/* One rank's share of a sharded stack in ONE stream-ordered call (SURVEY.md section 8 row b: trpx_encode_sharded /
+ * trpx_decode_sharded).  trpx_encode_sharded = trpx_encode of this rank's n_local frames (f_compress on its share of the stack,
+ * Terse.hpp:500-549; `out`, `local_offsets`, `status` exactly as trpx_encode leaves them) + trpx_gather_frame_offsets on the
+ * caller's communicator (`global_offsets`, `prolix_bits`, `rank_base` as above).  gather_stream: NULL -- the gather follows the
+ * encode on `stream`; another stream of the same device -- the gather runs there, ordered behind the encode by an event, so
+ * that what the caller enqueues on `stream` next (the decode of its own frames needs no global offset) overlaps the collective;
+ * the caller joins the two streams where it reads the table.  workspace: trpx_encode_sharded_workspace_bytes().
+ * trpx_decode_sharded expands this rank's frames -- frames [first_frame, first_frame + n_local) of the global stack, whose
+ * bytes it holds as `local_terse` -- from the GLOBAL offset table (prolix(it, frame) for its share, Terse.hpp:352-389; frames
+ * are independent, Terse.hpp:502-505): no collective, one small kernel in front of trpx_decode.  Errors of both:
+ * trpx_shard_last_error(). */
+size_t trpx_encode_sharded_workspace_bytes(int dtype, size_t n_values, size_t n_local, size_t n_slot, unsigned block, int world);
+int trpx_encode_sharded(void* comm, int dtype, const void* pixels, size_t n_values, size_t n_local, size_t n_slot, unsigned block,
+                        uint8_t* out, size_t out_capacity, uint64_t* local_offsets, uint32_t* status, uint64_t* global_offsets,
+                        uint32_t* prolix_bits, uint64_t* rank_base, void* workspace, size_t workspace_bytes, void* stream,
+                        void* gather_stream);
+size_t trpx_decode_sharded_workspace_bytes(int dtype, size_t n_values, size_t n_local, unsigned block);
+int trpx_decode_sharded(int stream_signed, int out_dtype, const uint8_t* local_terse, size_t local_bytes, const uint64_t* global_offsets,
+                        size_t first_frame, size_t n_values, size_t n_local, unsigned block, void* pixels_out, uint32_t* status,
+                        void* workspace, size_t workspace_bytes, void* stream);
 /* A communicator for callers that have none: rank 0 makes the 128-byte id, every rank gets it by its own means
  * (MPI, torch.distributed, a file) and calls trpx_comm_init with the GPU it will use already selected. */
 int trpx_comm_unique_id(void* id128);

@@ -54,8 +54,8 @@ def _bench(extra_env, *flags):
 
 @pytest.mark.gpu
 def test_bench_distributed_branch_runs_on_one_rank():
-    """The code an N > 1 run takes -- init_process_group("nccl"), the C-ABI size gather on its own RCCL communicator and side
-    stream, the barrier + MAX-over-ranks timing, the global-offset assertions behind the timed region -- rehearsed with one
+    """The code an N > 1 run takes -- init_process_group("nccl"), the single-call C-ABI sharded encode (trpx_encode_sharded: the rank's encode + the size gather on its own RCCL communicator
+    and side stream, trpx_decode_sharded behind the timed region), the barrier + MAX-over-ranks timing, the global-offset assertions behind the timed region -- rehearsed with one
     rank in a fresh process (TRPX_BENCH_FORCE_DIST=1), next to the plain run of the same workload: the gather must be the
     C-ABI one and may not cost the step more than 10 % (frames are independent, Terse.hpp:502-505: nothing but the sizes
     is exchanged)."""
@@ -63,7 +63,7 @@ def test_bench_distributed_branch_runs_on_one_rank():
     plain = _bench({}, *flags)
     forced = _bench({"TRPX_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"}, *flags)
     assert plain["config"]["size_gather"] is None
-    assert "trpx_gather_frame_offsets" in forced["config"]["size_gather"], forced["config"]
+    assert "trpx_encode_sharded" in forced["config"]["size_gather"], forced["config"]
     assert forced["n_gpus"] == 1 and forced["scaling"] == "weak"
     assert "byte-identical" in forced["oracle_check"]
     assert forced["value"] > 0.9 * plain["value"], (forced["value"], plain["value"])

@@ -305,6 +305,16 @@ def test_cpp_drop_in_example(gpu, tmp_path):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_cpp_sharded_example(gpu):
+    """trpx_encode_sharded / trpx_decode_sharded called from C++ on a one-rank RCCL communicator (tests/cpp/sharded_example.cpp):
+    the stack equals trpx::Terse's single-process encode of the same frames, the pixels come back exactly."""
+    exe = os.path.join(ROOT, "tests", "cpp", "sharded_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK sharded example" in r.stdout, r.stdout + r.stderr
+
+
 def test_integration_md_snippets_run(gpu):
     """INTEGRATION.md section 2's patched bodies inside a stand-in for the reference class (tests/cpp/integration_snippets.cpp)."""
     exe = os.path.join(ROOT, "tests", "cpp", "integration_snippets")
@@ -320,7 +330,9 @@ def test_decode_index_side_channel(gpu, oracle):
     both encoder paths)."""
     import torch
     from trpx_amd import codec, _lib
-    for dt, n, frames in ((np.uint16, 512 * 512, 9), (np.int32, 700 * 700, 3), (np.uint16, 12 * 1024 * 3 + 16, 5)):
+    # (frames of more than 32 K blocks: trpx_build_index takes the index route's one walk of many short parts, decode_part.hip)
+    for dt, n, frames in ((np.uint16, 512 * 512, 9), (np.int32, 700 * 700, 3), (np.uint16, 12 * 1024 * 3 + 16, 5),
+                          (np.int32, 1030 * 1065, 4), (np.uint16, 1500 * 1500 + 7, 3)):
         px = codec.synth(dt, 11, frames, n, device=gpu)
         for path in (0, 1):
             _lib.lib().trpx_set_encode_path(path)
@@ -709,6 +721,50 @@ def test_sharded_c_abi_size_gather_over_rccl(gpu, oracle):
         assert rb.cpu().numpy().tolist() == [0, int(want_go[700]), int(want_go[700])]
     finally:
         g.close()
+
+
+def test_sharded_single_call_entry_points(gpu, oracle):
+    """SURVEY row b: trpx_encode_sharded (this rank's trpx_encode + the size gather on the caller's communicator, in one
+    stream-ordered call, the gather optionally on a second stream) and trpx_decode_sharded (this rank's frames expanded from the
+    GLOBAL offset table) on a real one-rank RCCL communicator: the stack is the oracle's, the table the local offsets, the
+    pixels exact; then the decode with a table in which this rank's frames do not start at byte 0 (ranks in front of it)."""
+    import torch
+    from trpx_amd import codec, sharded, _lib
+    frames, n = 41, 96 * 96 + 5
+    px = codec.synth(np.uint16, 9, frames, n, device=gpu)
+    want, sizes, opb = oracle.encode_stack(px.cpu().numpy())
+    sc = sharded.ShardedCodec(frames, n, np.uint16, gpu)
+    try:
+        side = torch.cuda.Stream(device=gpu)
+        for gs in (None, side, None, side):                              # same buffers call after call, both stream arrangements
+            goffs, base, pb = sc.encode(px, gather_stream=gs)
+            torch.cuda.synchronize()
+            assert int(sc.status[0]) == 0 and int(pb) == opb and int(base) == 0
+            assert int(goffs[-1]) == want.size and torch.equal(goffs, sc.local_offsets)
+            assert sc.out[: want.size].cpu().numpy().tobytes() == want.tobytes()
+        back = torch.zeros((frames, n), dtype=torch.uint16, device=gpu)
+        _, sd = sc.decode(back)
+        torch.cuda.synchronize()
+        assert int(sd[0]) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
+        # a global table with 7 frames of other ranks in front of this rank's: trpx_decode_sharded(first_frame = 7)
+        L = _lib.lib()
+        front = torch.tensor(np.concatenate([[0], np.cumsum(np.arange(1000, 1007))]), dtype=torch.int64, device=gpu)
+        table = torch.cat([front[:-1], sc.local_offsets + front[-1]])
+        back.zero_()
+        ws = torch.empty(L.trpx_decode_sharded_workspace_bytes(_lib.U16, n, frames, 12), dtype=torch.uint8, device=gpu)
+        st = torch.empty(8, dtype=torch.int32, device=gpu)
+        rc = L.trpx_decode_sharded(0, _lib.U16, sc.out.data_ptr(), sc.out.numel(), table.data_ptr(), 7, n, frames, 12, back.data_ptr(),
+                                   st.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and int(st[0]) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16))
+        # argument checks: a workspace that is too small, no communicator
+        assert L.trpx_decode_sharded(0, _lib.U16, sc.out.data_ptr(), sc.out.numel(), table.data_ptr(), 7, n, frames, 12, back.data_ptr(),
+                                     st.data_ptr(), ws.data_ptr(), 64, None) == _lib.ERR_CAPACITY
+        assert L.trpx_encode_sharded(None, _lib.U16, px.data_ptr(), n, frames, frames, 12, sc.out.data_ptr(), sc.out.numel(),
+                                     sc.local_offsets.data_ptr(), sc.status.data_ptr(), sc.global_offsets.data_ptr(), None, None,
+                                     sc.ws_e.data_ptr(), sc.ws_e.numel(), None, None) == _lib.ERR_INVALID_ARG
+    finally:
+        sc.close()
 
 
 def test_lookback_timeout_falls_back_to_two_pass(gpu, oracle, tmp_path):

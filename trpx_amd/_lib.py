@@ -55,6 +55,10 @@ SYMBOLS = {
     "trpx_frame_offsets_host": (_I, [_P, _SZ, _SZ, _SZ, _U, _U, _P, _I]),
     "trpx_gather_workspace_bytes": (_SZ, [_SZ, _I]),
     "trpx_gather_frame_offsets": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P, _SZ, _P]),
+    "trpx_encode_sharded_workspace_bytes": (_SZ, [_I, _SZ, _SZ, _SZ, _U, _I]),
+    "trpx_encode_sharded": (_I, [_P, _I, _P, _SZ, _SZ, _SZ, _U, _P, _SZ, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "trpx_decode_sharded_workspace_bytes": (_SZ, [_I, _SZ, _SZ, _U]),
+    "trpx_decode_sharded": (_I, [_I, _I, _P, _SZ, _P, _SZ, _SZ, _SZ, _U, _P, _P, _P, _SZ, _P]),
     "trpx_gather_pack": (_I, [_P, _SZ, _SZ, _P, _P, _P]),
     "trpx_gather_scan": (_I, [_P, _I, _SZ, _P, _P, _P, _P]),
     "trpx_comm_unique_id": (_I, [_P]),

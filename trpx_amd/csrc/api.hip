@@ -88,14 +88,17 @@ int g_decode_path = [] {
     return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3
            : strcmp(e, "parts") == 0 ? 4 : 0;
 }();
-struct IdxLayout { size_t group_off, widths, seg, defer, total; };
+struct IdxLayout { size_t group_off, widths, seg, defer, parts, part_ws, total; };
 IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     IdxLayout l;
     l.group_off = 0;
     l.widths = trpx::align_up(8 * n_frames * (size_t)g.n_tiles, 16);
     l.seg = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);   // scratch of trpx_build_index's walk
     l.defer = l.seg + trpx::seg_workspace_bytes(g, n_frames);                 // list of the frames the per-frame walker hands over
-    l.total = l.defer + trpx::defer_bytes(n_frames);
+    l.parts = l.defer + trpx::defer_bytes(n_frames);                          // large frames: the index route's part table and scratch (decode_part.hip)
+    const size_t P = trpx::chain_parts_per_frame(g, n_frames);
+    l.part_ws = l.parts + (P > 1 ? trpx::align_up(sizeof(trpx::PartDesc) * n_frames * P, 256) : 0);
+    l.total = l.part_ws + trpx::chain_workspace_bytes(g, n_frames);
     return l;
 }
 struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, parts, part_ws, total; };
@@ -354,6 +357,13 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     a.defer = reinterpret_cast<uint32_t*>(static_cast<char*>(index) + il.defer + trpx::kDeferFront);
     // frames of < 2^26 bits: the per-frame decoder's walker writes the index (the conditions of trpx_decode's per-frame route)
     a.index_per_frame = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) + (1u << 17) < (1ull << 26) && g_decode_path != 2;
+    // frames of more than 32 K blocks: the index route's one walk of many short parts (decode_part.hip), unless the tiled route is forced
+    a.parts_per_frame = trpx::chain_parts_per_frame(g, n_frames);
+    a.chain = a.parts_per_frame > 1u && n_frames * (uint64_t)a.parts_per_frame < 0x7FFFFFFFull && g_decode_path != 2 && g_decode_path != 4;
+    if (a.chain) {
+        a.parts = reinterpret_cast<trpx::PartDesc*>(static_cast<char*>(index) + il.parts);
+        a.part_ws = static_cast<char*>(index) + il.part_ws;
+    } else a.parts_per_frame = 1;
     HIP_TRY(trpx::launch_walk_only(a, (uint32_t)(8 * trpx_dtype_size(dtype)), clear_status, static_cast<hipStream_t>(stream)));
     return TRPX_OK;
 }

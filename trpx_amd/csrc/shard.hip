@@ -182,6 +182,87 @@ int trpx_gather_scan(const uint64_t* all_messages, int world, size_t n_slot, uin
     return e == hipSuccess ? TRPX_OK : shard_fail(TRPX_ERR_HIP, "trpx_gather_scan", hipGetErrorString(e));
 }
 
+// ---- one call per rank: encode + size gather / decode from the global offsets ---------------------------------------------------
+namespace {
+// local_offsets[i] = global_offsets[first + i] - global_offsets[first]: this rank's frames inside its own stack
+__global__ __launch_bounds__(trpx::kThreads) void k_rebase_offsets(const uint64_t* __restrict__ global_offsets, uint64_t first, uint32_t n,
+                                                                  uint64_t* __restrict__ local_offsets) {
+    const uint64_t base = global_offsets[first];
+    for (uint32_t i = blockIdx.x * trpx::kThreads + threadIdx.x; i <= n; i += gridDim.x * trpx::kThreads)
+        local_offsets[i] = global_offsets[first + i] - base;
+}
+struct SideEvent {                                            // one cached event per calling thread (no allocation per call)
+    hipEvent_t ev = nullptr;
+    int device = -1;
+    ~SideEvent() { if (ev) (void)hipEventDestroy(ev); }
+};
+thread_local SideEvent t_side;
+}  // namespace
+
+size_t trpx_encode_sharded_workspace_bytes(int dtype, size_t n_values, size_t n_local, size_t n_slot, unsigned block, int world) {
+    const size_t e = trpx_encode_workspace_bytes(dtype, n_values, n_local, block), g = trpx_gather_workspace_bytes(n_slot, world);
+    return e && g ? trpx::align_up(e, 256) + g : 0;
+}
+
+int trpx_encode_sharded(void* comm, int dtype, const void* pixels, size_t n_values, size_t n_local, size_t n_slot, unsigned block,
+                        uint8_t* out, size_t out_capacity, uint64_t* local_offsets, uint32_t* status, uint64_t* global_offsets,
+                        uint32_t* prolix_bits, uint64_t* rank_base, void* workspace, size_t workspace_bytes, void* stream,
+                        void* gather_stream) {
+    const Rccl& R = rccl();
+    if (!R.ok) return shard_fail(TRPX_ERR_UNSUPPORTED, "trpx_encode_sharded", R.why);
+    if (!comm || !workspace || n_local == 0 || n_local > n_slot) return shard_fail(TRPX_ERR_INVALID_ARG, "trpx_encode_sharded", "bad argument");
+    int world = 0;
+    const ncclResult_t rc = R.CommCount(static_cast<ncclComm_t>(comm), &world);
+    if (rc != ncclSuccess) return shard_fail(TRPX_ERR_HIP, "ncclCommCount", R.GetErrorString(rc));
+    const size_t e_bytes = trpx::align_up(trpx_encode_workspace_bytes(dtype, n_values, n_local, block), 256);
+    const size_t g_bytes = trpx_gather_workspace_bytes(n_slot, world);
+    if (e_bytes == 0 || workspace_bytes < e_bytes + g_bytes) return shard_fail(TRPX_ERR_CAPACITY, "trpx_encode_sharded", "workspace too small");
+    // this rank's frames: the reference's f_compress on its share of the stack (Terse.hpp:500-549), bytes kept locally
+    int r = trpx_encode(dtype, pixels, n_values, n_local, block, out, out_capacity, local_offsets, status, workspace, e_bytes, stream);
+    if (r != TRPX_OK) return shard_fail(r, "trpx_encode_sharded", trpx_last_error_string());
+    hipStream_t gs = static_cast<hipStream_t>(stream);
+    if (gather_stream && gather_stream != stream) {
+        // the gather on the caller's second stream, behind the encode: whatever the caller enqueues on `stream` next (the decode of
+        // its own frames needs no global offset) runs beside the collective; the caller joins the two streams where it needs the table
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return shard_fail(TRPX_ERR_HIP, "trpx_encode_sharded", "hipGetDevice");
+        if (!t_side.ev || t_side.device != dev) {
+            if (t_side.ev) (void)hipEventDestroy(t_side.ev);
+            t_side.ev = nullptr;
+            if (hipEventCreateWithFlags(&t_side.ev, hipEventDisableTiming) != hipSuccess) return shard_fail(TRPX_ERR_HIP, "trpx_encode_sharded", "hipEventCreate");
+            t_side.device = dev;
+        }
+        gs = static_cast<hipStream_t>(gather_stream);
+        if (hipEventRecord(t_side.ev, static_cast<hipStream_t>(stream)) != hipSuccess || hipStreamWaitEvent(gs, t_side.ev, 0) != hipSuccess)
+            return shard_fail(TRPX_ERR_HIP, "trpx_encode_sharded", "event fork");
+    }
+    return trpx_gather_frame_offsets(comm, local_offsets, n_local, n_slot, status, global_offsets, prolix_bits, rank_base,
+                                     static_cast<char*>(workspace) + e_bytes, g_bytes, gs);
+}
+
+size_t trpx_decode_sharded_workspace_bytes(int dtype, size_t n_values, size_t n_local, unsigned block) {
+    const size_t d = trpx_decode_workspace_bytes(dtype, n_values, n_local, block);
+    return d ? trpx::align_up(d, 256) + trpx::align_up(8 * (n_local + 1), 256) : 0;
+}
+
+int trpx_decode_sharded(int stream_signed, int out_dtype, const uint8_t* local_terse, size_t local_bytes, const uint64_t* global_offsets,
+                        size_t first_frame, size_t n_values, size_t n_local, unsigned block, void* pixels_out, uint32_t* status,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!global_offsets || !workspace || n_local == 0 || n_local > 0x7FFFFFF0ull || (uintptr_t)global_offsets % 8 || (uintptr_t)workspace % 8)
+        return shard_fail(TRPX_ERR_INVALID_ARG, "trpx_decode_sharded", "bad argument");
+    const size_t d_bytes = trpx::align_up(trpx_decode_workspace_bytes(out_dtype, n_values, n_local, block), 256);
+    if (d_bytes == 0 || workspace_bytes < d_bytes + trpx::align_up(8 * (n_local + 1), 256))
+        return shard_fail(TRPX_ERR_CAPACITY, "trpx_decode_sharded", "workspace too small");
+    uint64_t* local_offsets = reinterpret_cast<uint64_t*>(static_cast<char*>(workspace) + d_bytes);
+    hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)((n_local + 1 + trpx::kThreads - 1) / trpx::kThreads)), dim3(trpx::kThreads), 0,
+                       static_cast<hipStream_t>(stream), global_offsets, (uint64_t)first_frame, (uint32_t)n_local, local_offsets);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return shard_fail(TRPX_ERR_HIP, "trpx_decode_sharded", hipGetErrorString(e));
+    const int r = trpx_decode(stream_signed, out_dtype, local_terse, local_bytes, local_offsets, n_values, n_local, block, pixels_out, status,
+                              workspace, d_bytes, stream);
+    return r == TRPX_OK ? TRPX_OK : shard_fail(r, "trpx_decode_sharded", trpx_last_error_string());
+}
+
 int trpx_comm_unique_id(void* id128) {
     const Rccl& R = rccl();
     if (!R.ok) return shard_fail(TRPX_ERR_UNSUPPORTED, "trpx_comm_unique_id", R.why);

@@ -135,3 +135,53 @@ class RcclSizeGather:
         if self.comm:
             self._L.trpx_comm_destroy(self.comm)
             self.comm = None
+
+
+class ShardedCodec(RcclSizeGather):
+    """One rank's share of a sharded stack through the single-call C ABI: `encode()` = `trpx_encode_sharded` (this rank's frames
+    encoded + the size gather over RCCL, optionally on a second stream so that the caller's next work overlaps the
+    collective), `decode()` = `trpx_decode_sharded` (this rank's frames expanded from the GLOBAL offset table).  Equal shards
+    of `frames_per_rank` frames; buffers allocated once.  GPU only."""
+
+    def __init__(self, frames_per_rank: int, n_values: int, dtype, device, group=None, block: int = 12):
+        super().__init__(frames_per_rank, device, group)
+        from . import codec
+        self._codec = codec
+        self.n_values, self.block = int(n_values), int(block)
+        self.tdt = codec.torch_dtype(dtype)
+        self.code = codec.dtype_code(self.tdt)
+        device = torch.device(device)
+        L = self._L
+        cap = (self.f * L.trpx_worst_case_bytes(self.code, self.n_values, self.block) + 15) // 16 * 16
+        self.out = torch.empty(cap, dtype=torch.uint8, device=device)
+        self.local_offsets = torch.empty(self.f + 1, dtype=torch.int64, device=device)
+        self.status = torch.empty(self._lib.STATUS_WORDS, dtype=torch.int32, device=device)
+        self.dec_status = torch.empty(self._lib.STATUS_WORDS, dtype=torch.int32, device=device)
+        self.ws_e = torch.empty(L.trpx_encode_sharded_workspace_bytes(self.code, self.n_values, self.f, self.f, self.block, self.world),
+                                dtype=torch.uint8, device=device)
+        self.ws_d = torch.empty(L.trpx_decode_sharded_workspace_bytes(self.code, self.n_values, self.f, self.block), dtype=torch.uint8, device=device)
+
+    def encode(self, pixels: torch.Tensor, gather_stream: "torch.cuda.Stream | None" = None):
+        """pixels: [frames_per_rank, n_values] on this rank's GPU.  Stream-ordered on the current stream (the gather on
+        `gather_stream` if given).  Returns (global_offsets, my_base, prolix_bits) as views of internal buffers."""
+        assert pixels.is_cuda and pixels.shape[0] == self.f and pixels[0].numel() == self.n_values and pixels.dtype == self.tdt
+        st = torch.cuda.current_stream(pixels.device).cuda_stream
+        with torch.cuda.device(pixels.device):
+            self._check(self._L.trpx_encode_sharded(self.comm, self.code, pixels.data_ptr(), self.n_values, self.f, self.f, self.block,
+                                                    self.out.data_ptr(), self.out.numel(), self.local_offsets.data_ptr(), self.status.data_ptr(),
+                                                    self.global_offsets.data_ptr(), self.prolix.data_ptr(), self.rank_base.data_ptr(),
+                                                    self.ws_e.data_ptr(), self.ws_e.numel(), st,
+                                                    gather_stream.cuda_stream if gather_stream is not None else None))
+        return self.global_offsets, self.rank_base[self.rank], self.prolix[0]
+
+    def decode(self, out: torch.Tensor, stream_signed: bool | None = None):
+        """Expands this rank's frames (the bytes `encode` left in self.out) from the global offset table into `out`."""
+        assert out.is_cuda and out.numel() == self.f * self.n_values and out.dtype == self.tdt
+        if stream_signed is None:
+            stream_signed = bool(self._L.trpx_dtype_is_signed(self.code))
+        st = torch.cuda.current_stream(out.device).cuda_stream
+        with torch.cuda.device(out.device):
+            self._check(self._L.trpx_decode_sharded(int(stream_signed), self.code, self.out.data_ptr(), self.out.numel(),
+                                                    self.global_offsets.data_ptr(), self.rank * self.f, self.n_values, self.f, self.block,
+                                                    out.data_ptr(), self.dec_status.data_ptr(), self.ws_d.data_ptr(), self.ws_d.numel(), st))
+        return out, self.dec_status
