@@ -1441,6 +1441,33 @@ def test_encoder_workspace_between_calls(gpu, oracle):
     assert enc() == 0 and enc() == 0
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.int16])
+def test_encoder_frames_two_bytes_behind_a_dword(gpu, oracle, dtype):
+    """Stacks of 16-bit frames with an odd pixel count (513 x 511, ...): every second frame starts 2 bytes behind a dword
+    boundary and is loaded through k_encode_fused_mis2's realigned loads (dword-aligned loads from the dword in front + funnel
+    shifts, encode_fused.hip: load_raw_mis2); and a stack whose FIRST pixel sits there (every frame but the first realigned).
+    Byte-identical to the oracle (Terse.hpp:500-549), incl. frames with a partial last block and tiles' halo blocks."""
+    import torch
+    from trpx_amd import codec
+    rng = np.random.RandomState(3)
+    for n, frames, shift in ((513 * 511, 9, 0), (12 * 1024 * 3 + 7, 6, 0), (300 * 300, 5, 1), (12 * 2048 + 1, 4, 1)):
+        a = rng.poisson(2.0, (frames, n)).astype(np.int64)
+        a[:, ::4099] = 3000
+        if np.dtype(dtype).kind == "i":
+            a = a - 2
+        a = a.astype(dtype)
+        want = oracle.encode_stack(a)[0]
+        flat = torch.zeros(frames * n + 8, dtype=torch.int16, device=gpu)
+        flat[shift: shift + frames * n] = torch.from_numpy(a.view(np.int16).reshape(-1)).to(gpu)
+        px = flat[shift: shift + frames * n].view(frames, n)
+        px = px.view(torch.uint16) if np.dtype(dtype).kind == "u" else px
+        assert px.data_ptr() % 4 == 2 * shift
+        enc = codec.encode(px)
+        torch.cuda.synchronize()
+        enc.check()
+        assert enc.stack().cpu().numpy().tobytes() == want.tobytes(), (dtype, n, frames, shift)
+
+
 def test_default_workspace_is_not_remembered(gpu, oracle):
     """codec.encode() without workspace= allocates its scratch itself and lets it die with the Encoded object: the library
     must not remember that memory as a clean workspace (torch's allocator hands the block to the next tensor).  Encode, drop,

@@ -352,7 +352,9 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
     // Poisson(3) counts too.  Only the first kind gets the flag (a walk that stops instead of starting again, k_chain_walk):
     // there a false chain may not merge for a whole part; in the others it merges within a few K bits, and a stopped part
     // costs its repair a whole part's walk (71 of 4200 parts stopped: the repair launch 236 instead of ~20 us).
-    return most12 >= 40u ? PartState{X, kPartWeak | kPartRuns} : plain;
+    // (32-bit pixels: from 24 on -- their parts hold half the blocks per bit, a stopped part's repair is a short walk (65 us for
+    // eight 4096^2 frames' parts, where two walks that kept starting again for 100 Kbits made k_chain_walk 187 instead of ~100 us))
+    return most12 >= (max_w > 16u ? 24u : 40u) ? PartState{X, kPartWeak | kPartRuns} : plain;
 }
 
 // Walks the chain from (pos, w) and counts the blocks that start in front of frame bit T; leaves the state at the first block
@@ -377,7 +379,7 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
                                           PartCk* __restrict__ ck, uint32_t ck_every, uint32_t& n_ck, bool tolerant,
                                           uint32_t ck_cap = kPartCk, bool stop_dense = true, uint8_t* __restrict__ ent = nullptr,
                                           uint32_t ent_cap = 1u, bool abort_illegal = false, uint32_t prio_span = 0u,
-                                          uint32_t* __restrict__ exp_out = nullptr) {
+                                          uint32_t* __restrict__ exp_out = nullptr, bool ratio_stop = false) {
     const uint32_t lane = (uint32_t)lane_id();
     uint32_t b = 0, n_exp = 0, b_ref = 0, exp_ref = 0;
     uint32_t ck_next = ck ? pos + ck_every : 0xFFFFFFFFu;
@@ -388,6 +390,12 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
             if (n_ck < ck_cap && lane == 0) ck[n_ck] = PartCk{pos, w_prev, b};
             n_ck = n_ck < ck_cap ? n_ck + 1u : n_ck;
             ck_next = pos + ck_every;
+            if (ratio_stop) {
+                // (run-dominated locales, k_chain_walk: more than 35 % explicit headers over a checkpoint interval is a chain that is
+                // not the frame's -- a false chain reads one at every other block -- even if it has not read an illegal width yet)
+                if (b - b_ref >= 32u && (n_exp - exp_ref) * 20u > (b - b_ref) * 7u) { dense = true; break; }
+                b_ref = b; exp_ref = n_exp;
+            }
             if (prio_span) {
                 // The SIMD's arbiter serves equal-priority waves oldest first: of the ~17 walkers of a CU the last to arrive finished
                 // at 115 - 137 us, the median at 65 (eight 4096 x 4096 frames, tools/chain_stamps.py) -- and a walker alone on its SIMD
@@ -1011,7 +1019,9 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
         // data: false chains merge within a few K bits, and a stopped part costs its repair a whole part's walk, the repair launch's
         // critical path: 233 against 15 us for 200 x (1030 x 1065) Poisson(3) counts --, kChainPatience bits where runs lie nearby or
         // the start was a run guess, which is then a wrong one: run-dominated data)
-        const uint32_t patience = (s.w & kPartWeak) != 0u && (s.w & kPartRuns) == 0u ? 0xFFFFFFFFu : kChainPatience;
+        // (... and even there not for ever: a chain that still reads illegal widths a quarter of the part in is one of the few --
+        // two of eight 4096^2 frames' 4352 -- that will not merge in time: 184 against 70 us)
+        const uint32_t patience = (s.w & kPartWeak) != 0u && (s.w & kPartRuns) == 0u ? (t.pos - X) / 4u : kChainPatience;
 #ifdef TRPX_CHAIN_STAMPS
         st_c = __builtin_amdgcn_s_memrealtime();
 #endif
