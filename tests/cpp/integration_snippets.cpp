@@ -99,6 +99,21 @@ int sharded_step(ncclComm_t comm, int world, const void* d_pixels, size_t n_valu
     return 0;
 }
 
+// INTEGRATION.md section 4, the single-call form (ABI version 3)
+int sharded_single_call(ncclComm_t comm, int world, int rank, const void* d_pixels, size_t n_values, size_t frames_per_rank, uint8_t* d_out,
+                        size_t cap, uint64_t* d_local_offsets, uint32_t* d_status, uint64_t* d_global_offsets, uint32_t* d_prolix_bits,
+                        uint64_t* d_rank_base, void* d_ws_e, void* d_ws_d, void* d_pixels_back, hipStream_t stream, hipStream_t side_stream) {
+// [snippet:sharded1]
+    size_t ws_e = trpx_encode_sharded_workspace_bytes(TRPX_U16, n_values, frames_per_rank, /*n_slot*/ frames_per_rank, 12, world);
+    trpx_encode_sharded(comm, TRPX_U16, d_pixels, n_values, frames_per_rank, frames_per_rank, 12, d_out, cap, d_local_offsets, d_status,
+                        d_global_offsets, d_prolix_bits, d_rank_base, d_ws_e, ws_e, stream, /*gather_stream*/ side_stream /* or NULL */);
+    size_t ws_d = trpx_decode_sharded_workspace_bytes(TRPX_U16, n_values, frames_per_rank, 12);
+    trpx_decode_sharded(/*stream_signed*/ 0, TRPX_U16, d_out, cap, d_global_offsets, /*first_frame*/ rank * frames_per_rank, n_values,
+                        frames_per_rank, 12, d_pixels_back, d_status, d_ws_d, ws_d, stream);
+// [/snippet]
+    return 0;
+}
+
 int main() {
     std::vector<std::uint16_t> a(5000), b(5000), out(5000);
     std::iota(a.begin(), a.end(), 0);

@@ -139,7 +139,7 @@ def test_integration_md_code_blocks_are_the_compiled_snippets():
     cpp = open(os.path.join(ROOT, "tests", "cpp", "integration_snippets.cpp")).read()
     doc = [ln.strip() for ln in open(os.path.join(ROOT, "INTEGRATION.md")).read().splitlines()]
     snippets = re.findall(r"// \[snippet:(\w+)\]\n(.*?)// \[/snippet\]", cpp, flags=re.S)
-    assert {n for n, _ in snippets} == {"include", "f_compress", "prolix", "sharded"}
+    assert {n for n, _ in snippets} == {"include", "f_compress", "prolix", "sharded", "sharded1"}
     for name, body in snippets:
         at = 0
         for ln in (x.strip() for x in body.splitlines()):
