@@ -11,11 +11,12 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 DT = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32]
 TDT = {np.uint8: torch.uint8, np.int8: torch.int8, np.uint16: torch.uint16, np.int16: torch.int16, np.uint32: torch.uint32, np.int32: torch.int32}
 t0 = time.time()
+n_large = n_fallback = 0
 for c in range(cases):
     dt = np.dtype(DT[rng.randint(6)])
     top = 8 * dt.itemsize - (2 if dt.kind == "i" else (1 if dt.itemsize == 4 else 0))      # inside the reference's validity domain (D3)
     n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3), 12 * 34000 + 8 * rng.randint(0, 3),
-                        513 * 511, 12 * 70000 + rng.randint(0, 12), 1030 * 1065]))            # (> 32768 blocks: cut into parts, decode_part.hip)
+                        513 * 511, 12 * 70000 + rng.randint(0, 12), 1030 * 1065, 1030 * 1065, 1475 * 1679, 2048 * 2048 + rng.randint(0, 3)]))   # (> 32768 blocks: cut into parts, decode_part.hip)
     n = max(1, n - rng.randint(0, 4) * rng.randint(0, 2))                                     # (half of the cases: no multiple of 4)
     frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else (int(rng.choice([1, 3, 130])) if n <= 12 * 34000 + 16 else int(rng.choice([1, 2, 9])))
     nblk = (n + 11) // 12
@@ -45,12 +46,17 @@ for c in range(cases):
         info = np.iinfo(dt)
         hit = rng.rand(*px.shape) < 0.002
         px = np.where(hit, rng.choice([info.min, info.max], size=px.shape), px).astype(dt)
+    if os.environ.get("TRPX_FUZZ_ONLY") and c not in [int(x) for x in os.environ["TRPX_FUZZ_ONLY"].split(",")]: continue   # (same random sequence, only these cases run)
+    if os.environ.get("TRPX_FUZZ_ONLY"): print(f"case {c}: kind {kind} {dt} n {n} frames {frames} widths {np.unique(hi)[:8]} pixels {np.unique(px)[:12]}", flush=True)
     want, sizes, pb = O.encode_stack(px)
     dpx = torch.from_numpy(px.view(np.dtype(f"i{dt.itemsize}"))).cuda().view(TDT[dt.type])
     enc = codec.encode(dpx); torch.cuda.synchronize(); enc.check()
     assert enc.stack().cpu().numpy().tobytes() == want.tobytes() and enc.prolix_bits() == pb, ("encode", c, dt, n, frames, kind)
     back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt); torch.cuda.synchronize()
     assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), ("decode", c, dt, n, frames, kind, int(st[0]))
+    if nblk > 32768:                                                                           # the index route's frames / those it handed to the other route
+        n_large += frames; n_fallback += int(st[2])
+        if int(st[2]) and os.environ.get("TRPX_FUZZ_VERBOSE"): print(f"  fallback: case {c} kind {kind} {dt} n {n} frames {frames}: {int(st[2])} frames", flush=True)
     if os.environ.get("TRPX_DECODE_PATH", "") != "basic":
         # the decode index three ways: the encoder's by-product, trpx_build_index, rebuilt from the group states -- all equal, all decode
         from trpx_amd import _lib
@@ -76,4 +82,4 @@ for c in range(cases):
         back, st = codec.decode(stack, enc_i.frame_offsets, n, frames, dt, index=rebuilt); torch.cuda.synchronize()
         assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), ("indexed decode", c, dt, n, frames, kind, int(st[0]))
     if c % 20 == 0: print(f"case {c} ok ({time.time() - t0:.0f} s)", flush=True)
-print(f"OK {cases} cases, path {os.environ.get('TRPX_DECODE_PATH', 'default')}")
+print(f"OK {cases} cases, path {os.environ.get('TRPX_DECODE_PATH', 'default')}; large frames {n_large}, of them handed to the fallback route {n_fallback}")

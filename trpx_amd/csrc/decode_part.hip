@@ -40,7 +40,10 @@
 
 namespace trpx {
 
-constexpr int kPartChunkDw = 2048;             // the walker's stream window: 8 KB
+#ifndef TRPX_PART_CHUNK_DW
+#define TRPX_PART_CHUNK_DW 2048
+#endif
+constexpr int kPartChunkDw = TRPX_PART_CHUNK_DW;   // the walker's stream window: 8 KB
 constexpr uint32_t kPartEvid = 32;             // header bits of evidence for a start inside a run: a stack has thousands of cuts x 10^5 candidates each, and with 24 bits one guess per stack WAS wrong -- on a chain that, in run-dominated data, does not merge before its part ends (the frame then takes the other route: +4 ms)
 constexpr uint32_t kPartSkip = 12;             // the start lies this many blocks inside the evidence (the bits in front of a run are 1 half the time)
 #ifndef TRPX_PART_SEARCH
@@ -183,7 +186,7 @@ __device__ __forceinline__ uint32_t part_header_phase(const uint32_t* __restrict
     n = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n), 63);
     if (n == 1u) return r0;
     if (n % 12u != 1u) return ~0u;
-    uint32_t found = ~0u, n_found = 0;
+    uint32_t found = ~0u, n_found = 0, found_any = ~0u, n_any = 0;
     for (uint32_t base = 0; base < s; base += kWave) {
         const uint32_t c = base + lane;                                        // candidate header: position r0 + c
         bool ok = c < s && part_pm_bit(pm, r0 + c);
@@ -204,11 +207,18 @@ __device__ __forceinline__ uint32_t part_header_phase(const uint32_t* __restrict
             classes += cnt == (uint32_t)kBlock ? 1u : 0u;
             top = cnt == (uint32_t)kBlock ? top + 1u : 0u;
         }
-        ok = ok && 1u + (uint32_t)kBlock * classes == n && top == classes;
-        const uint64_t m = __ballot(ok);
+        ok = ok && 1u + (uint32_t)kBlock * classes == n;
+        // (The grid shifted by one bit ALWAYS fits too: a pedestal's top bit w - 1 is constant, and seen from the position in
+        // front of the header -- the last field's top bit -- the header bits are class 0 and every class b is class b + 1.  What
+        // tells them apart: the block's width says bit w - 1 is set somewhere, in a pedestal everywhere -- the true grid HAS class
+        // w - 1, the shifted one only if bit w - 2 is constant too, and then the top-run rule decides.  Pixels 40 or 41: bits 5
+        // and 3 -- no top run, but only one grid with class 5.)
+        const uint64_t m_any = __ballot(ok && top >= 1u);
+        if (m_any) { n_any += (uint32_t)__builtin_popcountll(m_any); found_any = r0 + base + (uint32_t)__builtin_ctzll(m_any); }
+        const uint64_t m = __ballot(ok && top == classes);
         if (m) { n_found += (uint32_t)__builtin_popcountll(m); found = r0 + base + (uint32_t)__builtin_ctzll(m); }
     }
-    return n_found == 1u ? found : ~0u;
+    return n_any == 1u ? found_any : (n_found == 1u ? found : ~0u);
 }
 
 // reach: the search (and the state it returns) stays inside [X, X + reach).
@@ -305,7 +315,8 @@ __device__ __forceinline__ uint32_t part_try(PartWin& W, uint32_t* __restrict__ 
 // thirds of the cuts of a stack with a width change every nine blocks end here, and header-dense data, where no run exists, pays
 // for no more than this; (2) the width whose candidates survived longest, if they survived 20 header bits (chance: 2^-20 per
 // candidate, 32 K candidates), over the rest of the range: runs of that width exist nearby; (3) wider widths, one pass each,
-// only if no small width showed 16 bits of evidence (pedestals, wide data).  A cut that ends without a run warms up instead.
+// only if no small width has runs here (fewer than 20 positions of a pass with 12 header bits 1: pedestals, wide data --
+// header-dense narrow data shows 20 and more and mostly skips this stage).  A cut that ends without a run starts from a plain guess.
 __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t* __restrict__ s_pm, uint32_t X, uint32_t limit,
                                                  uint32_t max_w, uint32_t reach) {
     const uint32_t lane = (uint32_t)lane_id();
@@ -317,12 +328,13 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
     uint32_t passes = kPartSearch;
     while (passes && (uint64_t)X + 2048ull * passes + (uint64_t)kPartEvid * s_max + 128u > (uint64_t)limit) --passes;   // too close to the frame's end
     while (passes && 2048ull * passes + (uint64_t)kPartSkip * s_max > (uint64_t)reach) --passes;
-    if (passes == 0u) return plain;
+    if (X + 256u > limit) return plain;
     part_fill(W, s_chunk, X);
     {
         const uint32_t a = lane < 4u ? part_bits(W, s_chunk, X + 32u * lane) : 0xFFFFFFFFu;
-        if (!__ballot(a != 0xFFFFFFFFu)) return PartState{X, 0u};            // inside a run of empty blocks
+        if (!__ballot(a != 0xFFFFFFFFu)) return PartState{X, 0u};            // inside a run of empty blocks (parts of any size: an all-zero frame's are short)
     }
+    if (passes == 0u) return plain;
     const uint32_t w1 = max_w < 8u ? max_w : 8u, p1 = passes < 2u ? passes : 2u;
     uint32_t best_w = 0, best_d = 0, most12 = 0;
     for (uint32_t w = 1; w <= w1; ++w)
@@ -339,7 +351,7 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
             const uint32_t q = part_try(W, s_chunk, s_pm, X + 2048u * pass, best_w, d, n12);
             if (q != ~0u) return PartState{q, best_w};
         }
-    if (best_d < 16u)
+    if (most12 < 20u)                                                         // (no small width has runs here: wide data, a pedestal -- whose payload shows up to 16 by itself)
         for (uint32_t w = w1 + 1u; w <= max_w; ++w) {
             uint32_t d, n12;
             const uint32_t q = part_try(W, s_chunk, s_pm, X, w, d, n12);
@@ -354,6 +366,9 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
     // costs its repair a whole part's walk (71 of 4200 parts stopped: the repair launch 236 instead of ~20 us).
     // (32-bit pixels: from 24 on -- their parts hold half the blocks per bit, a stopped part's repair is a short walk (65 us for
     // eight 4096^2 frames' parts, where two walks that kept starting again for 100 Kbits made k_chain_walk 187 instead of ~100 us))
+#ifdef TRPX_PART_STATS
+    if (lane == 0 && (X & 0xFFu) < 24u) printf("guess: no run behind %u: best width %u depth %u, most12 %u, passes %u, max_w %u, limit %u reach %u\n", X, best_w, best_d, most12, passes, max_w, limit, reach);
+#endif
     return most12 >= (max_w > 16u ? 24u : 40u) ? PartState{X, kPartWeak | kPartRuns} : plain;
 }
 
@@ -961,7 +976,7 @@ __device__ __forceinline__ PartFrame chain_frame(const uint8_t* __restrict__ ter
     if (!f.ok) return f;
     const uint32_t tail = f.limit > 16u * kChainTail ? kChainTail : f.limit / 16u;
     f.L = (f.limit - tail + (P - 2u)) / (P - 1u);
-    f.ok = f.L >= 1024u && tail > P;                                        // (a frame of a few bits per part: another route)
+    f.ok = f.L >= 128u && tail > P;                                         // (a frame of a few bits per part: another route; an all-zero 4096 x 4096 frame has 1 Kbit parts)
     return f;
 }
 
@@ -994,8 +1009,19 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
                                                       PartWalk* __restrict__ walks, PartCk* __restrict__ cks, uint8_t* __restrict__ ents,
                                                       [[maybe_unused]] uint32_t* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
-    const uint32_t frame = blockIdx.x / (P - 1u), p = blockIdx.x % (P - 1u);
+#ifdef TRPX_CHAIN_REVERSE
+    const uint32_t item = gridDim.x - 1u - blockIdx.x;
+#else
+    const uint32_t item = blockIdx.x;
+#endif
+    const uint32_t frame = item / (P - 1u), p = item % (P - 1u);
     const uint32_t lane = (uint32_t)lane_id();
+#ifdef TRPX_CHAIN_PRIO0
+    // (experiment: the later a workgroup is dispatched, the higher it starts)
+    if (4u * blockIdx.x >= 3u * gridDim.x) __builtin_amdgcn_s_setprio(3);
+    else if (2u * blockIdx.x >= gridDim.x) __builtin_amdgcn_s_setprio(2);
+    else if (4u * blockIdx.x >= gridDim.x) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef TRPX_CHAIN_STAMPS
     const uint64_t st_a = __builtin_amdgcn_s_memrealtime();
     uint64_t st_b = st_a, st_c = st_a;
