@@ -35,6 +35,9 @@ constexpr int kFrameThreads = kFrameWaves * kWave;
 #ifndef TRPX_FRAME_CHUNK_DW
 #define TRPX_FRAME_CHUNK_DW 2048
 #endif
+#ifndef TRPX_IDX_TOUCH
+#define TRPX_IDX_TOUCH 1        // MODE 1: the filler touches the stream lines of the super-step it has just laid out (A/B: make idxtouch)
+#endif
 template <typename T>
 struct FrameCfg {
 #ifdef TRPX_FRAME_GPW
@@ -240,9 +243,13 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
 #ifdef TRPX_DEC_STAMPS
     uint64_t st_work = 0, st_wait = 0, st_t0 = __builtin_readcyclecounter(), st_start = st_t0;
 #endif
+    [[maybe_unused]] uint32_t idx_touch = 0;
     for (uint32_t s = 0; s <= n_steps; ++s) {
         if (wave == 0) {
             if (IDX && s < n_steps) {
+#if TRPX_IDX_TOUCH
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_touch) : : "memory");     // (the touch loads of the super-step before: long back)
+#endif
                 // ---- positions from the index: H(b) for the super-step's blocks by a prefix sum over header + payload lengths ----
                 const uint32_t beg_b = step_begin(s);
                 const uint32_t end_nom = step_begin(s + 1u) < n_blocks ? step_begin(s + 1u) : n_blocks;
@@ -254,6 +261,7 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                 for (int i = 0; i < kIdxChunks; ++i) wq[i] = s_wnext[i * kWave + lane];
                 if (s + 1u < n_steps) idx_load(s + 1u, wn);
                 bool bad = false;
+                [[maybe_unused]] const uint32_t pos_begin = pos;
 #pragma unroll
                 for (int i = 0; i < kIdxChunks; ++i) {
                     const uint32_t b0 = beg_b + (uint32_t)i * kWave;
@@ -282,6 +290,20 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     bad = at_end ? !(pos <= limit && 1 + ((uint64_t)ppos0 + pos) / 8 == fe - fo) : !(ppos0 + pos == ppos1 && w_prev == pw1);
                 if (__ballot(bad) && lane == 0) s_err = 1u;
                 if (lane == 0) ent[b - beg_b] = (frame_sh + (pos <= limit ? pos : limit)) | (w_prev << kPosBits);
+#if TRPX_IDX_TOUCH
+                {
+                    // The stream lines of this super-step's blocks, one dword per 128-byte line and lane (64 lines = 8 KB per
+                    // instruction): the extraction waves load per lane and block, two overlapping 16-byte loads each, an iteration
+                    // from now -- with the lines in L2 by then they miss the vector cache only.  (The walker of MODE 0 pulls the
+                    // stream through its LDS window for the same effect; without it the extraction's requests queue up between
+                    // the texture-address unit and the vector cache whenever HBM answers late: the kernel's slow state,
+                    // profiles/r04_idx_gap.txt.)  The value is never used; the register is given up at the next super-step.
+                    const uint64_t a0 = (4u * frame_dw + ((frame_sh + pos_begin) >> 3)) & ~127ull;
+                    const uint64_t a1 = 4u * frame_dw + ((frame_sh + (pos <= limit ? pos : limit)) >> 3);
+                    for (uint64_t my = a0 + 128u * lane; my <= a1 && my + 4u <= terse_bytes; my += 128u * kWave)
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(idx_touch) : "v"(terse + my) : "memory");
+                }
+#endif
                 if (s + 1u < n_steps) idx_park(wn);
             } else if (s < n_steps) {
                 const uint32_t buf = s & 1u;
