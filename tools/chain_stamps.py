@@ -19,17 +19,23 @@ for _ in range(3):
 torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.uint32)[16:].reshape(nf, P, 8)[:, : P - 1].reshape(-1, 8)
 t0 = (s[:, 0] - s[:, 0].min()).astype(np.int64)
-setup, warm, walk, nfill, tfill, cnt, nck = (s[:, i].astype(np.int64) for i in range(1, 8))
+setup, warm, walk, nfill, link, cnt, nck = (s[:, i].astype(np.int64) for i in range(1, 8))
 end = t0 + setup + warm + walk
+end2 = end + link
 q = lambda a: "min %6.1f  p50 %6.1f  p90 %6.1f  max %6.1f" % tuple(np.percentile(a, [0, 50, 90, 100]) / 100.0)
 print(f"{leg}: {nf} frames x {P} parts, exact {torch.equal(back.view(torch.uint8), px.view(torch.uint8))}, status {int(st[0])}")
 print("  start  us:", q(t0))
-print("  setup  us:", q(setup))
-print("  warm   us:", q(warm), " (parts with a warm-up: %d)" % int((warm > 50).sum()))
+print("  guess  us:", q(setup))
+print("  wait   us:", q(warm), " (for the neighbour's start state)")
 print("  walk   us:", q(walk))
-print("  fills    : n p50 %d max %d,  us" % (np.median(nfill), nfill.max()), q(tfill))
-print("  end    us:", q(end), "  blocks per part p50 %d max %d, checkpoints p50 %d" % (np.median(cnt), cnt.max(), np.median(nck)))
+print("  link   us:", q(link), " (the wait for the neighbour's record + the walk into its part; links with work: %d)" % int((link > 300).sum()))
+print("  fills    : n p50 %d max %d" % (np.median(nfill), nfill.max()))
+print("  done   us:", q(end2))
+print("  walked us:", q(end), "  blocks per part p50 %d max %d, checkpoints p50 %d" % (np.median(cnt), cnt.max(), np.median(nck)))
 order = np.argsort(-walk)[:8]
 for i in order:
-    print("  slow part: frame %d part %d  walk %.1f us  warm %.1f us  blocks %d  checkpoints %d  fills %d" %
-          (i // (P - 1), i % (P - 1), walk[i] / 100.0, warm[i] / 100.0, cnt[i], nck[i], nfill[i]))
+    print("  slow part: frame %d part %d  walk %.1f us  link %.1f us  blocks %d  checkpoints %d  fills %d" %
+          (i // (P - 1), i % (P - 1), walk[i] / 100.0, link[i] / 100.0, cnt[i], nck[i], nfill[i]))
+order = np.argsort(-end2)[:6]
+for i in order:
+    print("  last done: frame %d part %d  walked at %.1f us  link %.1f us  done %.1f us" % (i // (P - 1), i % (P - 1), end[i] / 100.0, link[i] / 100.0, end2[i] / 100.0))

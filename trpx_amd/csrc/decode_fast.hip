@@ -199,9 +199,6 @@ hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint3
 
 // Fast path preconditions (checked by the caller): block = 12, frame offsets known, frames of < 2^32 bits (T-aligned pointers, any pixel count).
 hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
-    if (clear_status) {
-        zero_status(a.status, st);
-    }
     // the position-parallel walk; diagnostic builds: TRPX_WALK = lds keeps the one-wavefront-per-frame walk (A/B checks)
 #ifdef TRPX_DIAGNOSTICS
     static const bool lds_walk = getenv("TRPX_WALK") && strcmp(getenv("TRPX_WALK"), "lds") == 0;
@@ -211,13 +208,14 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
     if (!lds_walk && a.seg_ws && a.chain && a.parts && a.defer) {
         // large frames: one walk of many short parts writes the index (every frame through k_chain_index: narrow = false); the
         // frames where that does not work out are listed and get theirs from the position-parallel walk
-        hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st, reinterpret_cast<uint64_t*>(a.defer) - kDeferSlots * kDeferSlotWords,
-                           (uint64_t)(kDeferSlots * kDeferSlotWords + 1), reinterpret_cast<uint64_t*>(a.status), (uint64_t)0);
+        hipError_t e = launch_chain_zero(a, clear_status, st);
+        if (e != hipSuccess) return e;
         const uint32_t* mode = nullptr;
-        const hipError_t e = launch_build_index_chain(a, max_w, false, &mode, st);
+        e = launch_build_index_chain(a, max_w, false, &mode, st);
         if (e != hipSuccess) return e;
         return launch_seg_listed(a, max_w, st);
     }
+    if (clear_status) zero_status(a.status, st);
     if (!lds_walk && a.seg_ws && a.index_per_frame && a.defer)
         return launch_index_frames(max_w, a, false, st);        // (status cleared above if asked)
     if (!lds_walk && a.seg_ws) return launch_seg_walk(a, max_w, st);

@@ -862,14 +862,20 @@ hipError_t launch_decode_frames_indexed(int dtype, const DecodeArgs& a, const ui
 template <typename T>
 static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     uint32_t* defer = a.defer && a.seg_ws ? a.defer : nullptr;
-    hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st,
-                       defer ? reinterpret_cast<uint64_t*>(defer) - kDeferSlots * kDeferSlotWords : static_cast<uint64_t*>(nullptr),
-                       (uint64_t)(defer ? kDeferSlots * kDeferSlotWords + 1 : 0),
-                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)4);   // status block + the deferred-frame count and the stack statistics in front of it
+    const bool chain = a.chain && a.parts && a.parts_per_frame > 1u;
+    if (chain) {                                                              // (the same words and the index route's own, in one launch)
+        if (!defer) return hipErrorInvalidValue;
+        const hipError_t e = launch_chain_zero(a, true, st);
+        if (e != hipSuccess) return e;
+    } else
+        hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st,
+                           defer ? reinterpret_cast<uint64_t*>(defer) - kDeferSlots * kDeferSlotWords : static_cast<uint64_t*>(nullptr),
+                           (uint64_t)(defer ? kDeferSlots * kDeferSlotWords + 1 : 0),
+                           reinterpret_cast<uint64_t*>(a.status), (uint64_t)4);   // status block + the deferred-frame count and the stack statistics in front of it
     Profiler& prof = profiler();
     prof.begin();
     prof.mark(st);
-    if (a.chain && a.parts && a.parts_per_frame > 1u) {
+    if (chain) {
         // Large frames by the index route (decode_part.hip): one walk of many short parts writes the decode index, the frames
         // where that does not work out are listed and get theirs from the position-parallel walk, then every frame's tiles are
         // extracted with the widths given.

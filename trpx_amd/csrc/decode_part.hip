@@ -54,7 +54,8 @@ constexpr uint32_t kPartCk = 256;              // checkpoints per part
 constexpr uint32_t kPartWeak = 0x80000000u;    // PartState::w: a plain guess (not expected to be a state of the chain)
 constexpr uint32_t kPartAmbig = 0x40000000u;   //   ... because runs were found, but not which of their passing positions is the header's
 constexpr uint32_t kPartRuns = 0x20000000u;    //   ... (index route) although runs of equal widths lie nearby: run-dominated data, where a false chain is slow to merge
-constexpr uint32_t kPartFlags = kPartWeak | kPartAmbig | kPartRuns;
+constexpr uint32_t kPartReady = 0x10000000u;   //   (index route) the state has been published: k_chain_walk's wavefronts wait for their neighbour's
+constexpr uint32_t kPartFlags = kPartWeak | kPartAmbig | kPartRuns | kPartReady;
 
 struct PartState { uint32_t pos, w; };
 struct PartCk { uint32_t pos, w, cnt; };
@@ -70,6 +71,31 @@ struct PartFix {                               // what k_part_repair leaves per 
     uint32_t state;                            // 0: link closed, nothing done; 1: merged into the part's walk; 2: walked to T_p on its own; 3: failed
     uint32_t cnt, o_pos, o_w;                  // the part's block count (and, state 2, its end state) from the true start
 };
+
+// Checkpoints and walk records are read by OTHER wavefronts of the launch that writes them (index route: k_chain_walk's links), on
+// other XCDs: agent-scope atomic words -- write-through stores, loads that do not trust a cached line -- ordered by the record's
+// `published` bit alone.  (Fences instead write back or invalidate the XCD's whole L2, dirty with the walk's entries: measured,
+// 45 - 100 us per launch of 4000 wavefronts.)
+constexpr uint32_t kWalkPublished = 0x80000000u;   // PartWalk::flags
+#ifdef TRPX_PART_STATS
+constexpr uint64_t kChainWaitTicks = 3000000000ull;    // (diagnostic build: its printfs hold wavefronts up for milliseconds)
+#else
+constexpr uint64_t kChainWaitTicks = 25000000ull;      // how long a wavefront waits for another's word: 0.25 s of the 100 MHz counter
+#endif
+__device__ __forceinline__ void part_ck_store(PartCk* dst, const PartCk& c) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    __hip_atomic_store(d, c.pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, c.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 2, c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ PartCk part_ck_load(const PartCk* src) {
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(src);
+    PartCk c;
+    c.pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (wave-uniform address)
+    c.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    c.cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return c;
+}
 
 uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames) {
     if (g.n_blocks <= kPartMaxBlocks || n_frames == 0) return 1u;
@@ -104,8 +130,13 @@ size_t part_workspace_bytes(const FrameGeom& g, size_t n_frames) {
 // One LDS-DMA piece (see decode_frame.hip): lane l's 16 bytes at `src` land at LDS byte address lds_base + 16 * l.
 __device__ __forceinline__ void part_lds_dma16(const uint32_t* src_uniform, uint32_t lane_byte_offset, uint32_t lds_base) {
     uint32_t keep;
+    // (wave-uniform by construction; said again for the builds in which the compiler loses sight of it: "invalid operand")
+    const uint64_t a = (uint64_t)(uintptr_t)src_uniform;
+    const uint32_t* const src = reinterpret_cast<const uint32_t*>((uintptr_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
+                                                                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32)));
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_base);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_byte_offset), "s"(src_uniform), "s"(lds_base) : "memory");
+                 : "=&s"(keep) : "v"(lane_byte_offset), "s"(src), "s"(base) : "memory");
 }
 
 struct PartWin {                               // the frame's stream behind an LDS window
@@ -402,7 +433,7 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
     n_ck = 0;
     while (pos < T && !bad) {
         if (pos >= ck_next) {
-            if (n_ck < ck_cap && lane == 0) ck[n_ck] = PartCk{pos, w_prev, b};
+            if (n_ck < ck_cap && lane == 0) part_ck_store(ck + n_ck, PartCk{pos, w_prev, b});
             n_ck = n_ck < ck_cap ? n_ck + 1u : n_ck;
             ck_next = pos + ck_every;
             if (ratio_stop) {
@@ -451,6 +482,10 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
             uint32_t pw_max = pw_end - 63u * stride;
             uint32_t v_ls = __umul24(lane, stride);
             uint32_t s_bad = 0, t_first, t_h, t_t, t_p, t_a, t_bits;
+            // (the steps' state lives in scalar registers -- wave-uniform by construction, which the compiler cannot always see through
+            // the callers' loops: "illegal VGPR to SGPR copy" in some builds, not in others)
+            auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+            pw = uni(pw); pw_end = uni(pw_end); pw_max = uni(pw_max); stride = uni(stride); b = uni(b); n_exp = uni(n_exp); w_prev = uni(w_prev);
 #define TRPX_PART_STEP_ASM(ST_STEP, ST_WIDTH)                                                                                  \
                 "s_cmp_lt_i32 %[pw], %[pwmax]\n\t"                                                                             \
                 "s_cbranch_scc0 9f\n"                                                                                          \
@@ -518,6 +553,9 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
                 "9:\n"
             if constexpr (STORE) {
                 uint32_t t_eo, v_wv = w_prev;
+                const uint32_t capm1_u = uni(capm1), max_w_u = uni(max_w);
+                const uint64_t ent_a = (uint64_t)(uintptr_t)ent;
+                uint8_t* const ent_u = reinterpret_cast<uint8_t*>((uintptr_t)((uint64_t)uni((uint32_t)ent_a) | ((uint64_t)uni((uint32_t)(ent_a >> 32)) << 32)));
                 asm volatile(TRPX_PART_STEP_ASM("v_add_u32 %[eo], %[b], %[lane]\n\t"
                                                 "v_min_u32 %[eo], %[capm1], %[eo]\n\t"
                                                 "global_store_byte %[eo], %[wv], %[ebase]\n\t",
@@ -525,14 +563,15 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
                     : [pw] "+s"(pw), [b] "+s"(b), [nexp] "+s"(n_exp), [w] "+s"(w_prev), [stride] "+s"(stride), [pwmax] "+s"(pw_max),
                       [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
                       [a] "=&v"(t_a), [bits] "=&v"(t_bits), [eo] "=&v"(t_eo), [wv] "+v"(v_wv)
-                    : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w), [capm1] "s"(capm1), [ebase] "s"(ent)
+                    : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w_u), [capm1] "s"(capm1_u), [ebase] "s"(ent_u)
                     : "vcc", "scc", "memory", "v62", "v63");
             } else {
+                const uint32_t max_w_u = uni(max_w);
                 asm volatile(TRPX_PART_STEP_ASM("", "")
                     : [pw] "+s"(pw), [b] "+s"(b), [nexp] "+s"(n_exp), [w] "+s"(w_prev), [stride] "+s"(stride), [pwmax] "+s"(pw_max),
                       [ls] "+v"(v_ls), [bad] "+s"(s_bad), [first] "=&s"(t_first), [h] "=&s"(t_h), [t] "=&s"(t_t), [p] "=&v"(t_p),
                       [a] "=&v"(t_a), [bits] "=&v"(t_bits)
-                    : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w)
+                    : [lane] "v"(lane), [pwend] "s"(pw_end), [maxw] "s"(max_w_u)
                     : "vcc", "scc", "memory", "v62", "v63");
             }
 #undef TRPX_PART_STEP_ASM
@@ -954,7 +993,7 @@ struct ChainFix {                              // what k_chain_repair leaves per
 struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, total; };
 static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     ChainWs w;
-    w.states = 0;
+    w.states = 0;                                                             // [states, fixes): start states and walk records with their ready / published bits, cleared in front of every call (launch_chain_zero)
     w.walks = align_up(w.states + n_frames * P * sizeof(PartState), 256);
     w.fixes = align_up(w.walks + n_frames * P * sizeof(PartWalk), 256);
     w.cks = align_up(w.fixes + n_frames * P * sizeof(ChainFix), 256);
@@ -980,18 +1019,188 @@ __device__ __forceinline__ PartFrame chain_frame(const uint8_t* __restrict__ ter
     return f;
 }
 
-__global__ __launch_bounds__(kWave) void k_chain_guess(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                       const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
-                                                       PartState* __restrict__ states) {
+// The blocks of a part counted again from the true state (pos, w), checkpoint by checkpoint of the part's own walk: fast steps to
+// the next checkpoint's position (part_walk: it stops at the first block start at or behind it), and if the chain arrives IN the
+// checkpoint's state the two have merged -- the rest of that walk is this chain's.  Leaves the entries of the blocks it counted in
+// fix[] (part_walk<true>) as long as they fit.  Returns the ChainFix state.
+__device__ __forceinline__ uint32_t chain_rewalk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w, uint32_t T,
+                                                 uint32_t limit, uint32_t max_w, const PartCk* __restrict__ ck, uint32_t n_ck,
+                                                 uint32_t walk_cnt, uint8_t* __restrict__ fix, uint32_t fix_cap, ChainFix& x) {
+    uint32_t b = 0, k = 0;
+    bool fits = true, bad = false, dense = false;
+    for (;;) {
+        PartCk c{};
+        while (k < n_ck && (c = part_ck_load(ck + k)).pos <= pos) {
+            if (c.pos == pos && c.w == w) {                                   // (starts in a checkpoint: nothing to count)
+                x.b_merge = b; x.ck_cnt = c.cnt; x.cnt = b + (walk_cnt - c.cnt); x.n_fix = fits ? b + 1u : 0u;
+                return 1u;
+            }
+            ++k;
+        }
+        const uint32_t target = k < n_ck ? c.pos : T;                         // (c: checkpoint k, the first one behind pos)
+        uint32_t cnt = 0, n0 = 0;
+        if (fits && b + 160u < fix_cap)
+            part_walk<true>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false, fix + b, fix_cap - b);
+        else
+            part_walk<false>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false);
+        if (bad) return 3u;
+        b += cnt;
+        fits = fits && b + 1u < fix_cap;
+        if (k >= n_ck) break;                                                 // at T on its own
+    }
+    x.cnt = b; x.o_pos = pos; x.o_w = w; x.b_merge = b; x.ck_cnt = 0u; x.n_fix = fits ? b + 1u : 0u;
+    return 2u;
+}
+
+// A walk record / a start state of ANOTHER wavefront of this launch, once it has been published (bounded wait: a record that does
+// not come reads as a bad walk, a state as position 0 -- the link fails and the frame takes the other route).
+__device__ __forceinline__ PartWalk chain_walk_wait(const PartWalk* src) {
+    const uint64_t* d = reinterpret_cast<const uint64_t*>(src);
+    uint64_t v[4] = {0, 0, 0, 0};
+    if (lane_id() == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // cnt | flags << 32
+            if (((v[1] >> 32) & kWalkPublished) != 0u) break;
+            __builtin_amdgcn_s_sleep(64);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kChainWaitTicks) { v[1] = 1ull << 32; break; }   // 0.25 s: a bad walk
+        }
+        v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[2] = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[3] = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t u[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u[2 * i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v[i]);
+        u[2 * i + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v[i] >> 32));
+    }
+    PartWalk r;
+    __builtin_memcpy(&r, u, 32);
+    return r;
+}
+__device__ __forceinline__ void chain_walk_publish(PartWalk* dst, PartWalk r) {
+    static_assert(sizeof(PartWalk) == 32, "four 64-bit words");
+    r.flags |= kWalkPublished;
+    uint64_t v[4];
+    __builtin_memcpy(v, &r, 32);
+    uint64_t* d = reinterpret_cast<uint64_t*>(dst);
+    if (lane_id() == 0) {
+        __hip_atomic_store(d, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 2, v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 3, v[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the record's other words and the checkpoints (write-through) have arrived
+    if (lane_id() == 0) __hip_atomic_store(d + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ PartState chain_state_wait(const PartState* src) {
+    const uint64_t* d = reinterpret_cast<const uint64_t*>(src);
+    uint64_t v = 0;
+    if (lane_id() == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            v = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((v >> 32) & kPartReady) != 0u) break;
+            __builtin_amdgcn_s_sleep(32);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kChainWaitTicks) { v = 0; break; }           // 0.25 s of the 100 MHz counter
+        }
+    }
+    return PartState{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32))};
+}
+
+// The link INTO part p (1 <= p <= P - 2), by the wavefront that has just walked part p - 1 (`prev`: its record) and arrived in front
+// of it.  Closed -- the part's walk started where this chain arrives -- nothing is counted.  Open: the part's blocks are counted again
+// from here, checkpoint by checkpoint of the part's own walk, until the chains have merged (chain_rewalk).  A part whose walk stopped
+// on a false chain (flag 16) is counted as a whole (state 2: nothing to merge into), and the same wavefront goes on into the parts
+// behind it for as long as they are stopped parts: their own wavefronts, which cannot know the true end of a stopped part, leave the
+// link behind them alone.  Every part's ChainFix is written by exactly one wavefront.
+// (Until round 5 a launch of its own behind the walk: its critical path -- the longest-lived false chain of 4000, a part's restart
+// far into it, a stopped part -- was 47 us for eight 4096^2 frames and 130 us for 200 x (1030 x 1065) Poisson(3) frames, with the
+// GPU all but idle; here it falls into the slack every wavefront but the launch's slowest has.)
+__device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                const PartState* states, const PartWalk* walks, const PartCk* cks, ChainFix* __restrict__ fixes,
+                                                uint8_t* __restrict__ fixents, uint32_t fix_cap, uint32_t frame, uint32_t p, const PartWalk& prev,
+                                                PartFrame& f, uint32_t* __restrict__ s_chunk) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint64_t slot0 = (uint64_t)frame * P;
+    uint32_t pos = prev.o_pos, w = prev.o_w;                                  // the true end of the part in front (if ITS start was true: k_chain_resolve)
+    {   // arrives in the state the part's walk was started in: closed (a walk that began again behind an illegal width, or stopped,
+        // did so on a chain this one would then be too)
+        const PartState g = chain_state_wait(states + slot0 + p);
+        if ((prev.flags & 1u) != 0u || (g.pos == pos && (g.w & ~kPartFlags) == w)) {
+            if (lane == 0) fixes[slot0 + p] = ChainFix{};
+            return;
+        }
+    }
+    PartWalk mine = chain_walk_wait(walks + slot0 + p);
+#ifdef TRPX_PART_STATS
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (uint32_t cur = p;;) {
+        ChainFix x{};
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);             // (wave-uniform by construction)
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        const bool open = !(pos == mine.s_pos && w == mine.s_w) || (mine.flags & 16u) != 0u;
+        if (open) {
+            x.state = 3u;
+            const PartState t = chain_state_wait(states + slot0 + cur + 1u);
+            if (f.ok && (mine.flags & 1u) == 0u && pos < t.pos && t.pos < f.limit) {
+                const uint32_t n_ck = (mine.flags & 16u) != 0u ? 0u : (mine.n_ck < kChainCk ? mine.n_ck : kChainCk);   // (a stopped walk: nothing to merge into)
+                x.state = chain_rewalk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cks + (slot0 + cur) * kChainCk, n_ck, mine.cnt,
+                                       fixents + (slot0 + cur) * (uint64_t)fix_cap, fix_cap, x);
+                if (x.state == 1u && (mine.flags & 8u) != 0u) x.n_fix = 0u;  // (the part's own entries did not fit: nothing to splice onto)
+#ifdef TRPX_PART_STATS
+                if (x.state == 3u && lane == 0)
+                    printf("repair failed in its walk: frame %u part %u of %u at %u/%u target %u limit %u, own walk %u/%u -> %u/%u cnt %u n_ck %u flags %u\n",
+                           frame, cur, P, pos, w, t.pos, f.limit, mine.s_pos, mine.s_w, mine.o_pos, mine.o_w, mine.cnt, mine.n_ck, mine.flags);
+#endif
+            }
+        }
+        if (lane == 0) fixes[slot0 + cur] = x;
+#ifdef TRPX_PART_STATS
+        {
+            const uint64_t t_now = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && t_now - t_start > 30000u)
+                printf("slow repair: frame %u part %u (from %u) %u us: state %u cnt %u merge at %u (own block %u), own walk cnt %u n_ck %u flags %u start %u/%u, true start %u\n", frame, cur, p,
+                       (uint32_t)(t_now - t_start) / 100u, x.state, x.cnt, x.b_merge, x.ck_cnt, mine.cnt, mine.n_ck, mine.flags, mine.s_pos, mine.s_w, prev.o_pos);
+        }
+#endif
+        // on into the next part?  only behind a stopped part that this wavefront has counted to its end
+        if (x.state != 2u || (mine.flags & 16u) == 0u || cur + 1u > P - 2u) break;
+        ++cur;
+        mine = chain_walk_wait(walks + slot0 + cur);                          // (pos, w: the true end of the part just counted)
+    }
+}
+
+// One wavefront per part: its start state first -- a position inside a run of equal widths behind the cut, or a plain guess
+// (chain_guess) --, published for the wavefront of the part in front, whose walk ends there; then the walk to the start state of the
+// part behind, which that part's wavefront publishes.  (One launch instead of a guessing and a walking one: the waits are for a
+// wavefront that needs nothing from anybody -- a neighbour's guess is 15 .. 30 us of work from its dispatch --, bounded, and a
+// wavefront that gives up reports a bad walk: the frame takes the other route.)
+__global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                      const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
+                                                      uint32_t ent_cap, PartState* states, PartWalk* walks, PartCk* cks,
+                                                      uint8_t* __restrict__ ents, ChainFix* __restrict__ fixes, uint8_t* __restrict__ fixents,
+                                                      [[maybe_unused]] uint32_t* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
     __shared__ uint32_t s_pm[kWave + 2];
-    const uint32_t frame = blockIdx.x / P, p = blockIdx.x % P;
+    const uint32_t item = blockIdx.x;
+    const uint32_t frame = item / P, p = item % P;
     const uint32_t lane = (uint32_t)lane_id();
+#ifdef TRPX_CHAIN_STAMPS
+    const uint64_t st_a = __builtin_amdgcn_s_memrealtime();
+    uint64_t st_b = st_a, st_c = st_a;
+#endif
     if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
     if (lane < 2u) s_pm[kWave + lane] = 0u;
+    const uint64_t slot = (uint64_t)frame * P + p;
+    PartWalk r{};
+    r.flags = 1u;
+    PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
     PartState s{0u, 0u};                                                      // a frame starts at bit 0 with width 0 (Terse.hpp:359, :505)
     if (p != 0u) {
-        PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
         if (!f.ok) s = PartState{0u, kPartWeak};
         else {
             const uint32_t X = p * f.L;
@@ -1000,42 +1209,16 @@ __global__ __launch_bounds__(kWave) void k_chain_guess(const uint8_t* __restrict
             s = chain_guess(f.W, s_chunk, s_pm, X, f.limit, max_w, reach);
         }
     }
-    if (lane == 0) states[blockIdx.x] = s;
-}
-
-__global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                      const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
-                                                      uint32_t ent_cap, const PartState* __restrict__ states,
-                                                      PartWalk* __restrict__ walks, PartCk* __restrict__ cks, uint8_t* __restrict__ ents,
-                                                      [[maybe_unused]] uint32_t* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
-#ifdef TRPX_CHAIN_REVERSE
-    const uint32_t item = gridDim.x - 1u - blockIdx.x;
-#else
-    const uint32_t item = blockIdx.x;
-#endif
-    const uint32_t frame = item / (P - 1u), p = item % (P - 1u);
-    const uint32_t lane = (uint32_t)lane_id();
-#ifdef TRPX_CHAIN_PRIO0
-    // (experiment: the later a workgroup is dispatched, the higher it starts)
-    if (4u * blockIdx.x >= 3u * gridDim.x) __builtin_amdgcn_s_setprio(3);
-    else if (2u * blockIdx.x >= gridDim.x) __builtin_amdgcn_s_setprio(2);
-    else if (4u * blockIdx.x >= gridDim.x) __builtin_amdgcn_s_setprio(1);
-#endif
+    s.pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.pos);
+    s.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.w);
+    uint64_t* const sw = reinterpret_cast<uint64_t*>(states);
+    if (lane == 0)
+        __hip_atomic_store(sw + slot, (uint64_t)s.pos | ((uint64_t)(s.w | kPartReady) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the word is all there is to publish: no fence)
+    if (p + 1u == P) return;                                                  // (the frame's last part is walked by count: k_chain_index)
 #ifdef TRPX_CHAIN_STAMPS
-    const uint64_t st_a = __builtin_amdgcn_s_memrealtime();
-    uint64_t st_b = st_a, st_c = st_a;
-#endif
-    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
-    const uint64_t slot = (uint64_t)frame * P + p;
-    PartWalk r{};
-    r.flags = 1u;
-    PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
-    const PartState s = states[slot], t = states[slot + 1u];
-#ifdef TRPX_CHAIN_STAMPS
-    if (t.pos + s.pos == 0xFFFFFFFFu) return;                                 // (the loads have arrived)
     st_b = __builtin_amdgcn_s_memrealtime();
 #endif
+    const PartState t = chain_state_wait(states + slot + 1u);                 // (never came: t.pos = 0 -> a bad walk)
     if (f.ok && t.pos > s.pos && t.pos < f.limit) {
         uint32_t pos = s.pos, w = s.w & ~kPartFlags, cnt = 0, n_ck = 0;
         bool bad = false, dense = false, stopped = false;
@@ -1085,109 +1268,24 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
         r.o_pos = pos; r.o_w = w; r.cnt = cnt; r.n_ck = n_ck; r.pad = n_exp;
         r.flags = (bad ? 1u : 0u) | (cnt + 1u > ent_cap - 1u ? 8u : 0u) | (stopped ? 16u : 0u);   // 8: more blocks than entries; 16: stopped on a false chain
     }
-    if (lane == 0) walks[slot] = r;
+    chain_walk_publish(walks + slot, r);
+#ifdef TRPX_CHAIN_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint64_t st_d = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the link into the part behind (parts 1 .. P - 2; the last part's is checked by k_chain_index, which walks it by count) -- unless
+    // this walk stopped on a false chain: the wavefront that counts this part from its true start goes on through that link
+    if (p + 2u < P && (r.flags & 16u) == 0u)
+        chain_link_into(terse, terse_bytes, frame_offsets, max_w, P, states, walks, cks, fixes, fixents, ent_cap, frame, p + 1u, r, f, s_chunk);
 #ifdef TRPX_CHAIN_STAMPS
     if (lane == 0) {       // diagnostic build (tools/chain_stamps.py): a status block of 16 + 8 * parts words
         __builtin_amdgcn_s_waitcnt(0);
-        const uint64_t st_d = __builtin_amdgcn_s_memrealtime();
+        const uint64_t st_e = __builtin_amdgcn_s_memrealtime();
         uint32_t* o = stamps + 16 + 8 * slot;
         o[0] = (uint32_t)st_a; o[1] = (uint32_t)(st_b - st_a); o[2] = (uint32_t)(st_c - st_b); o[3] = (uint32_t)(st_d - st_c);
-        o[4] = f.W.n_fill; o[5] = f.W.t_fill; o[6] = r.cnt; o[7] = r.n_ck;
+        o[4] = f.W.n_fill; o[5] = (uint32_t)(st_e - st_d); o[6] = r.cnt; o[7] = r.n_ck;
     }
 #endif
-}
-
-// The blocks of a part counted again from the true state (pos, w), checkpoint by checkpoint of the part's own walk: fast steps to
-// the next checkpoint's position (part_walk: it stops at the first block start at or behind it), and if the chain arrives IN the
-// checkpoint's state the two have merged -- the rest of that walk is this chain's.  Leaves the entries of the blocks it counted in
-// fix[] (part_walk<true>) as long as they fit.  Returns the ChainFix state.
-__device__ __forceinline__ uint32_t chain_rewalk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w, uint32_t T,
-                                                 uint32_t limit, uint32_t max_w, const PartCk* __restrict__ ck, uint32_t n_ck,
-                                                 uint32_t walk_cnt, uint8_t* __restrict__ fix, uint32_t fix_cap, ChainFix& x) {
-    uint32_t b = 0, k = 0;
-    bool fits = true, bad = false, dense = false;
-    for (;;) {
-        while (k < n_ck && ck[k].pos <= pos) {
-            const PartCk c = ck[k];
-            if (c.pos == pos && c.w == w) {                                   // (starts in a checkpoint: nothing to count)
-                x.b_merge = b; x.ck_cnt = c.cnt; x.cnt = b + (walk_cnt - c.cnt); x.n_fix = fits ? b + 1u : 0u;
-                return 1u;
-            }
-            ++k;
-        }
-        const uint32_t target = k < n_ck ? ck[k].pos : T;
-        uint32_t cnt = 0, n0 = 0;
-        if (fits && b + 160u < fix_cap)
-            part_walk<true>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false, fix + b, fix_cap - b);
-        else
-            part_walk<false>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false);
-        if (bad) return 3u;
-        b += cnt;
-        fits = fits && b + 1u < fix_cap;
-        if (k >= n_ck) break;                                                 // at T on its own
-    }
-    x.cnt = b; x.o_pos = pos; x.o_w = w; x.b_merge = b; x.ck_cnt = 0u; x.n_fix = fits ? b + 1u : 0u;
-    return 2u;
-}
-
-// One wavefront per part 1 <= p <= P - 2: the link INTO part p.  A part whose walk stopped on a false chain (flag 16) is counted as
-// a whole from the true end of the part in front (state 2: nothing to merge into), and the same wavefront goes on into the parts
-// behind it for as long as they are stopped parts or do not start where it arrives: their own wavefronts, which cannot know the
-// true end of a stopped part, do nothing.  Every part's ChainFix is written by exactly one wavefront.
-__global__ __launch_bounds__(kWave) void k_chain_repair(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                        const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
-                                                        const PartState* __restrict__ states, const PartWalk* __restrict__ walks,
-                                                        const PartCk* __restrict__ cks, ChainFix* __restrict__ fixes,
-                                                        uint8_t* __restrict__ fixents, uint32_t fix_cap) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
-    const uint32_t frame = blockIdx.x / (P - 1u), p = blockIdx.x % (P - 1u);
-    const uint32_t lane = (uint32_t)lane_id();
-    if (p == 0u) return;                                                      // (part 0 starts in the true state)
-    const uint64_t slot0 = (uint64_t)frame * P;
-    const PartWalk prev = walks[slot0 + p - 1u];
-    if ((prev.flags & 16u) != 0u) return;                                     // the wavefront that counts the stopped part in front goes on into this one
-    PartWalk mine = walks[slot0 + p];
-    uint32_t pos = prev.o_pos, w = prev.o_w;                                  // the true end of the part in front (if ITS start was true: k_chain_resolve)
-    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
-    PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
-#ifdef TRPX_PART_STATS
-    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-#endif
-    for (uint32_t cur = p;;) {
-        ChainFix x{};
-        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);             // (wave-uniform by construction)
-        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-        const bool open = !(pos == mine.s_pos && w == mine.s_w) || (mine.flags & 16u) != 0u;
-        if (open && (prev.flags & 1u) == 0u) {
-            x.state = 3u;
-            const PartState t = states[slot0 + cur + 1u];
-            if (f.ok && (mine.flags & 1u) == 0u && pos < t.pos && t.pos < f.limit) {
-                const uint32_t n_ck = (mine.flags & 16u) != 0u ? 0u : (mine.n_ck < kChainCk ? mine.n_ck : kChainCk);   // (a stopped walk: nothing to merge into)
-                x.state = chain_rewalk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cks + (slot0 + cur) * kChainCk, n_ck, mine.cnt,
-                                       fixents + (slot0 + cur) * (uint64_t)fix_cap, fix_cap, x);
-                if (x.state == 1u && (mine.flags & 8u) != 0u) x.n_fix = 0u;  // (the part's own entries did not fit: nothing to splice onto)
-#ifdef TRPX_PART_STATS
-                if (x.state == 3u && lane == 0)
-                    printf("repair failed in its walk: frame %u part %u of %u at %u/%u target %u limit %u, own walk %u/%u -> %u/%u cnt %u n_ck %u flags %u\n",
-                           frame, cur, P, pos, w, t.pos, f.limit, mine.s_pos, mine.s_w, mine.o_pos, mine.o_w, mine.cnt, mine.n_ck, mine.flags);
-#endif
-            }
-        }
-        if (lane == 0) fixes[slot0 + cur] = x;
-#ifdef TRPX_PART_STATS
-        {
-            const uint64_t t_now = __builtin_amdgcn_s_memrealtime();
-            if (lane == 0 && t_now - t_start > 8000u)
-                printf("slow repair: frame %u part %u (from %u) %u us: state %u cnt %u merge at %u (own block %u), own walk cnt %u n_ck %u flags %u start %u/%u, true start %u\n", frame, cur, p,
-                       (uint32_t)(t_now - t_start) / 100u, x.state, x.cnt, x.b_merge, x.ck_cnt, mine.cnt, mine.n_ck, mine.flags, mine.s_pos, mine.s_w, prev.o_pos);
-        }
-#endif
-        // on into the next part?  only behind a stopped part that this wavefront has counted to its end
-        if (x.state != 2u || (mine.flags & 16u) == 0u || cur + 1u > P - 2u) break;
-        ++cur;
-        mine = walks[slot0 + cur];                                            // (pos, w: the true end of the part just counted)
-    }
 }
 
 // list[0] = count, list[1 + i] = frame (bit 31 clear: the position-parallel walk may look for runs).
@@ -1196,12 +1294,13 @@ __global__ __launch_bounds__(kWave) void k_chain_repair(const uint8_t* __restric
 // walk, but one that hides under the extraction where explicit headers are rare -- 200 x (1030 x 1065) u16 synth-v1: 106 us
 // against k_chain_index 24 + k_unpack_tiles 122; where they are frequent the walker is that kernel's bound: Poisson(3) counts
 // 200 against 25 + 131).  `narrow` (8 / 16-bit pixels): by the frame's explicit headers per block; 32-bit pixels: always 1.
-__global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restrict__ walks, const ChainFix* __restrict__ fixes, FrameGeom g,
-                                                         uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
-                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
-    const uint32_t frame = blockIdx.x, lane = (uint32_t)lane_id();
-    const PartWalk* __restrict__ wf = walks + (uint64_t)frame * P;
-    const ChainFix* __restrict__ xf = fixes + (uint64_t)frame * P;
+// One wavefront per frame.
+__device__ __forceinline__ void chain_resolve_frame(const PartWalk* walks, const ChainFix* fixes, const FrameGeom& g, uint32_t frame,
+                                                    uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
+                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    const uint32_t lane = (uint32_t)lane_id();
+    const PartWalk* wf = walks + (uint64_t)frame * P;
+    const ChainFix* xf = fixes + (uint64_t)frame * P;
     PartDesc* __restrict__ pf = parts + (uint64_t)frame * P;
     bool ok = true;
     uint32_t running = 0, n_explicit = 0;
@@ -1285,6 +1384,12 @@ __global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restr
             atomicAdd(status + 2, 1u);                                        // status[2]: frames the index route handed to the position-parallel walk
         }
     }
+}
+
+__global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restrict__ walks, const ChainFix* __restrict__ fixes, FrameGeom g,
+                                                         uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
+                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    chain_resolve_frame(walks, fixes, g, blockIdx.x, P, narrow, parts, mode, list, status);
 }
 
 // Walks `nb` blocks from (pos, w_prev) -- general steps, Terse.hpp:360-372 -- and writes their widths to wf[0 .. nb) and the bit
@@ -1460,7 +1565,28 @@ __global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict
     }
 }
 
-// Fills a.widths / a.tile_off for every frame that works out and lists the others in a.defer.
+// The words the index route needs cleared in front of every call: the status block (if asked), the deferred-frame count and the
+// stack statistics in front of it, and the route's start states and walk records (ChainWs: [states, fixes)).  One launch.
+__global__ __launch_bounds__(kThreads) void k_chain_zero(uint64_t* __restrict__ p, uint64_t n, uint64_t* __restrict__ q, uint64_t m,
+                                                         uint64_t* __restrict__ r, uint64_t k) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kThreads;
+    for (uint64_t i = i0; i < k; i += stride) r[i] = 0ull;
+    for (uint64_t i = i0; i < n; i += stride) p[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x < m) q[threadIdx.x] = 0ull;
+}
+hipError_t launch_chain_zero(const DecodeArgs& a, bool clear_status, hipStream_t st) {
+    const uint32_t P = a.parts_per_frame;
+    if (P < 4u || !a.part_ws || !a.defer) return hipErrorInvalidValue;
+    const ChainWs l = chain_ws_layout(a.geom, a.n_frames, P);
+    const uint64_t k = l.fixes / 8;
+    hipLaunchKernelGGL(k_chain_zero, dim3((uint32_t)((k + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, st,
+                       reinterpret_cast<uint64_t*>(a.defer) - kDeferSlots * kDeferSlotWords, (uint64_t)(kDeferSlots * kDeferSlotWords + 1),
+                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0), reinterpret_cast<uint64_t*>(a.part_ws), k);
+    return hipGetLastError();
+}
+
+// Fills a.widths / a.tile_off for every frame that works out and lists the others in a.defer.  The caller has cleared the route's
+// words (launch_chain_zero) earlier on the stream.
 hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool narrow, const uint32_t** frame_mode, hipStream_t st) {
     const uint32_t P = a.parts_per_frame;
     if (P < 4u || !a.parts || !a.part_ws || !a.defer) return hipErrorInvalidValue;
@@ -1474,12 +1600,8 @@ hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool na
     uint8_t* fixents = reinterpret_cast<uint8_t*>(ws + l.fixents);
     uint32_t* modes = reinterpret_cast<uint32_t*>(ws + l.modes);
     const uint32_t cap = chain_ent_cap(a.geom.n_blocks, P);
-    const dim3 links(a.n_frames * (P - 1u));
-    hipLaunchKernelGGL(k_chain_guess, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, states);
-    hipLaunchKernelGGL(k_chain_walk, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, cap,
-                       static_cast<const PartState*>(states), walks, cks, ents, a.status);
-    hipLaunchKernelGGL(k_chain_repair, links, dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P,
-                       static_cast<const PartState*>(states), static_cast<const PartWalk*>(walks), static_cast<const PartCk*>(cks), fixes, fixents, cap);
+    hipLaunchKernelGGL(k_chain_walk, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, cap,
+                       states, walks, cks, ents, fixes, fixents, a.status);
     hipLaunchKernelGGL(k_chain_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartWalk*>(walks),
                        static_cast<const ChainFix*>(fixes), a.geom, P, narrow ? 1u : 0u, a.parts, modes, a.defer, a.status);
     hipLaunchKernelGGL(k_chain_index, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
