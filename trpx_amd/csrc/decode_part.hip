@@ -1025,9 +1025,10 @@ __device__ __forceinline__ PartFrame chain_frame(const uint8_t* __restrict__ ter
 // fix[] (part_walk<true>) as long as they fit.  Returns the ChainFix state.
 __device__ __forceinline__ uint32_t chain_rewalk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w, uint32_t T,
                                                  uint32_t limit, uint32_t max_w, const PartCk* __restrict__ ck, uint32_t n_ck,
-                                                 uint32_t walk_cnt, uint8_t* __restrict__ fix, uint32_t fix_cap, ChainFix& x) {
-    uint32_t b = 0, k = 0;
-    bool fits = true, bad = false, dense = false;
+                                                 uint32_t walk_cnt, uint8_t* __restrict__ fix, uint32_t fix_cap, ChainFix& x,
+                                                 uint32_t b = 0, bool fits = true) {   // (b, fits: blocks already counted by chain_walk_ahead)
+    uint32_t k = 0;
+    bool bad = false, dense = false;
     for (;;) {
         PartCk c{};
         while (k < n_ck && (c = part_ck_load(ck + k)).pos <= pos) {
@@ -1093,6 +1094,50 @@ __device__ __forceinline__ void chain_walk_publish(PartWalk* dst, PartWalk r) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the record's other words and the checkpoints (write-through) have arrived
     if (lane_id() == 0) __hip_atomic_store(d + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ... without waiting: false if the record is not there yet
+__device__ __forceinline__ bool chain_walk_poll(const PartWalk* src, PartWalk& r) {
+    const uint64_t* d = reinterpret_cast<const uint64_t*>(src);
+    uint64_t v[4] = {0, 0, 0, 0};
+    if (lane_id() == 0) {
+        v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((v[1] >> 32) & kWalkPublished) != 0u) {
+            v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[2] = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[3] = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    uint32_t u[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u[2 * i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v[i]);
+        u[2 * i + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v[i] >> 32));
+    }
+    __builtin_memcpy(&r, u, 32);
+    return (r.flags & kWalkPublished) != 0u;
+}
+// The part behind, counted from the true state while its own wavefront is still walking it: kChainAhead bits at a time, its record
+// polled in between.  True: the record has come (`mine`); the chain stands at (pos, w), b blocks in, and chain_rewalk goes on from
+// there with the record's checkpoints.  False: the chain is at T (or `bad`) and the record still is not there.
+constexpr uint32_t kChainAhead = 8192;
+__device__ __forceinline__ bool chain_walk_ahead(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w, uint32_t T, uint32_t limit,
+                                                 uint32_t max_w, uint8_t* __restrict__ fix, uint32_t fix_cap, uint32_t& b, bool& fits, bool& bad,
+                                                 const PartWalk* rec, PartWalk& mine) {
+    bool dense = false;
+    for (;;) {
+        if (chain_walk_poll(rec, mine)) return true;
+        if (pos >= T || bad) return false;
+        const uint32_t target = T - pos > kChainAhead ? pos + kChainAhead : T;
+        uint32_t cnt = 0, n0 = 0;
+        if (fits && b + 160u < fix_cap)
+            part_walk<true>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false, fix + b, fix_cap - b);
+        else
+            part_walk<false>(W, s_chunk, pos, w, target, limit, max_w, cnt, bad, dense, nullptr, 0u, n0, false, 0u, false);
+        b += cnt;
+        fits = fits && b + 1u < fix_cap;
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    }
+}
 __device__ __forceinline__ PartState chain_state_wait(const PartState* src) {
     const uint64_t* d = reinterpret_cast<const uint64_t*>(src);
     uint64_t v = 0;
@@ -1125,15 +1170,17 @@ __device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ ters
     const uint32_t lane = (uint32_t)lane_id();
     const uint64_t slot0 = (uint64_t)frame * P;
     uint32_t pos = prev.o_pos, w = prev.o_w;                                  // the true end of the part in front (if ITS start was true: k_chain_resolve)
-    {   // arrives in the state the part's walk was started in: closed (a walk that began again behind an illegal width, or stopped,
-        // did so on a chain this one would then be too)
-        const PartState g = chain_state_wait(states + slot0 + p);
-        if ((prev.flags & 1u) != 0u || (g.pos == pos && (g.w & ~kPartFlags) == w)) {
-            if (lane == 0) fixes[slot0 + p] = ChainFix{};
-            return;
-        }
+    // arrives in the state the part's walk was started in: closed (a walk that began again behind an illegal width, or stopped, did
+    // so on a chain this one would then be too)
+    const PartState g = chain_state_wait(states + slot0 + p);
+    if ((prev.flags & 1u) != 0u || (g.pos == pos && (g.w & ~kPartFlags) == w)) {
+        if (lane == 0) fixes[slot0 + p] = ChainFix{};
+        return;
     }
-    PartWalk mine = chain_walk_wait(walks + slot0 + p);
+    // A part that started from a plain guess (no run behind its cut: header-dense data, wide data) is not on the frame's chain until
+    // it has merged with it, so this link is open: the count from here starts at once, ahead of the part's record (chain_walk_ahead)
+    // -- waiting for it first left the launch's last wavefronts idle for 60 us and more, behind the slowest walks of all.
+    const bool ahead = (g.w & kPartWeak) != 0u;
 #ifdef TRPX_PART_STATS
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1142,14 +1189,21 @@ __device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ ters
         pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);             // (wave-uniform by construction)
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-        const bool open = !(pos == mine.s_pos && w == mine.s_w) || (mine.flags & 16u) != 0u;
+        const PartState t = chain_state_wait(states + slot0 + cur + 1u);
+        const bool can_walk = f.ok && pos < t.pos && t.pos < f.limit;
+        const uint32_t pos_in = pos, w_in = w;
+        uint8_t* const fix = fixents + (slot0 + cur) * (uint64_t)fix_cap;
+        uint32_t b = 0;
+        bool fits = true, bad = false, have = false;
+        PartWalk mine{};
+        if (ahead && cur == p && can_walk) have = chain_walk_ahead(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, fix, fix_cap, b, fits, bad, walks + slot0 + cur, mine);
+        if (!have) mine = chain_walk_wait(walks + slot0 + cur);
+        const bool open = !(pos_in == mine.s_pos && w_in == mine.s_w) || (mine.flags & 16u) != 0u;
         if (open) {
             x.state = 3u;
-            const PartState t = chain_state_wait(states + slot0 + cur + 1u);
-            if (f.ok && (mine.flags & 1u) == 0u && pos < t.pos && t.pos < f.limit) {
+            if (can_walk && !bad && (mine.flags & 1u) == 0u) {
                 const uint32_t n_ck = (mine.flags & 16u) != 0u ? 0u : (mine.n_ck < kChainCk ? mine.n_ck : kChainCk);   // (a stopped walk: nothing to merge into)
-                x.state = chain_rewalk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cks + (slot0 + cur) * kChainCk, n_ck, mine.cnt,
-                                       fixents + (slot0 + cur) * (uint64_t)fix_cap, fix_cap, x);
+                x.state = chain_rewalk(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cks + (slot0 + cur) * kChainCk, n_ck, mine.cnt, fix, fix_cap, x, b, fits);
                 if (x.state == 1u && (mine.flags & 8u) != 0u) x.n_fix = 0u;  // (the part's own entries did not fit: nothing to splice onto)
 #ifdef TRPX_PART_STATS
                 if (x.state == 3u && lane == 0)
@@ -1157,7 +1211,7 @@ __device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ ters
                            frame, cur, P, pos, w, t.pos, f.limit, mine.s_pos, mine.s_w, mine.o_pos, mine.o_w, mine.cnt, mine.n_ck, mine.flags);
 #endif
             }
-        }
+        } else { pos = pos_in; w = w_in; }                                    // (closed after all: what was counted ahead is dropped)
         if (lane == 0) fixes[slot0 + cur] = x;
 #ifdef TRPX_PART_STATS
         {
@@ -1169,8 +1223,7 @@ __device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ ters
 #endif
         // on into the next part?  only behind a stopped part that this wavefront has counted to its end
         if (x.state != 2u || (mine.flags & 16u) == 0u || cur + 1u > P - 2u) break;
-        ++cur;
-        mine = chain_walk_wait(walks + slot0 + cur);                          // (pos, w: the true end of the part just counted)
+        ++cur;                                                                // (pos, w: the true end of the part just counted)
     }
 }
 
