@@ -1401,6 +1401,43 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_index_route_waits_are_bounded(gpu, tmp_path):
+    """The index route's walk is ONE launch in which every part's wavefront waits for words its neighbours publish: the start
+    state of the part behind (its walk ends there) and that part's walk record (the link into it) -- decode_part.hip,
+    k_chain_walk.  The waits are bounded; a wavefront that gives up reports a bad walk / a failed link and the frame takes the
+    position-parallel route.  Test build (make chain_timeout): frame 0's part 3 never publishes its start state, frame 1's
+    part 5 never its record, the bound is 2 ms.  Both frames must be handed over (status[2]), nothing may hang, the pixels
+    are exact -- header-dense frames (every link open, records waited for) and frames whose cuts lie in runs."""
+    variant = os.path.join(ROOT, "tools", "variants", "libtrpx_chain_timeout.so")
+    if not os.path.exists(variant):
+        pytest.skip("test variant not built (make -C trpx_amd/csrc chain_timeout)")
+    script = tmp_path / "t.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from trpx_amd import codec, _lib, workloads
+n, frames = 1030 * 1065, 6
+for kind in ("poisson3", "synth"):
+    px = workloads.poisson_u16(3.0, 0, frames, n, device="cuda") if kind == "poisson3" else codec.synth(np.uint16, 3, frames, n, device="cuda")
+    enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+    P = _lib.lib().trpx_decode_parts_per_frame(codec.dtype_code(np.uint16), n, frames, 12)
+    assert P > 8, P
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+    torch.cuda.synchronize()
+    s = st.cpu().numpy()
+    assert s[0] == 0 and torch.equal(back, px), (kind, s)
+    assert 2 <= s[2] <= 3, (kind, s)          # frames 0 and 1 (and no others but by the data's own doing)
+    idx = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+    back2, st2 = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16, index=idx)
+    torch.cuda.synchronize()
+    assert int(st2[0]) == 0 and torch.equal(back2, px), kind
+print("OK")
+""")
+    r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_encoder_workspace_between_calls(gpu, oracle):
     """The single-pass encoder's descriptor words are cleared by the call's last kernel, and the library skips the clearing
     launch for a workspace it remembers as clean (include/trpx_hip.h, "Workspaces between calls").  Same workspace call after
