@@ -3,7 +3,7 @@
 # Per benchmark leg (tools/leg_prof.py): rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc passes
 # (no trace domains next to --pmc), the program directly behind `--`.  tools/legs_json.py turns the directory into one json.
 out=$1; shift
-legs=${@:-synth:free synth:idx synth:enc noisy:free noisy:idx poisson3:free poisson3:idx midsize:free midsize:idx midsize_p3:free oddsize:free c4:free c4:idx c4:enc mid2048:free}
+legs=${@:-synth:free synth:idx synth:enc noisy:free noisy:idx poisson3:free poisson3:idx midsize:free midsize:idx midsize_p3:free oddsize:free c4:free c4:idx c4:enc mid2048:free mid2048_p3:free}
 mkdir -p $out
 export TMPDIR=/tmp
 for lm in $legs; do
