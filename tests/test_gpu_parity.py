@@ -1401,6 +1401,34 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_many_large_frames_stay_whole(gpu, oracle):
+    """Stacks of 768 frames and more keep frames of more than 32 K blocks on the per-frame route (one workgroup per frame,
+    header-dense frames handed to the one-wavefront position-parallel walk) instead of cutting them into parts
+    (encode_kernels.hpp: single_part_blocks; Terse.hpp:352-389 either way): 768 frames of 640 x 640 pixels -- 34 134 blocks --,
+    Poisson(3) counts (every frame handed over) and synth-v1 (none), index-free decode, index built from the stream, decode
+    with it; two frames against the oracle."""
+    import torch
+    from trpx_amd import codec, _lib, workloads
+    n, frames = 640 * 640, 768
+    assert _lib.lib().trpx_decode_parts_per_frame(codec.dtype_code(np.uint16), n, frames, 12) == 1
+    assert _lib.lib().trpx_decode_parts_per_frame(codec.dtype_code(np.uint16), n, frames - 1, 12) > 1
+    for kind in ("poisson3", "synth"):
+        px = workloads.poisson_u16(3.0, 0, frames, n, device=gpu) if kind == "poisson3" else codec.synth(np.uint16, 5, frames, n, device=gpu)
+        enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+        offs = enc.frame_offsets.cpu().numpy()
+        for f in (0, frames - 1):
+            want = oracle.encode_stack(px[f:f + 1].cpu().numpy())[0]
+            assert bytes(enc.data[int(offs[f]): int(offs[f + 1])].cpu().numpy()) == bytes(want), (kind, f)
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and torch.equal(back, px), kind
+        idx = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+        back2, st2 = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16, index=idx)
+        torch.cuda.synchronize()
+        assert int(st2[0]) == 0 and torch.equal(back2, px), kind
+        del px, enc, back, back2, idx
+
+
 def test_index_route_waits_are_bounded(gpu, tmp_path):
     """The index route's walk is ONE launch in which every part's wavefront waits for words its neighbours publish: the start
     state of the part behind (its walk ends there) and that part's walk record (the link into it) -- decode_part.hip,

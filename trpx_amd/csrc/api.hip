@@ -88,6 +88,14 @@ int g_decode_path = [] {
     return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3
            : strcmp(e, "parts") == 0 ? 4 : 0;
 }();
+// $TRPX_SINGLE_PART = "frames,blocks": stacks of that many frames and more keep frames of up to that many blocks on the per-frame
+// route (encode_kernels.hpp: single_part_blocks; tuning runs -- the built-in rule otherwise)
+[[maybe_unused]] static const int g_single_part_env = [] {
+    const char* e = getenv("TRPX_SINGLE_PART");
+    unsigned f = 0, b = 0;
+    if (e && sscanf(e, "%u,%u", &f, &b) == 2) trpx::set_single_part_rule(f, b);
+    return 0;
+}();
 struct IdxLayout { size_t group_off, widths, seg, defer, parts, part_ws, total; };
 IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
     IdxLayout l;

@@ -793,8 +793,22 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
 }
 template <typename T>
 static hipError_t launch_decode_units_indexed_t(const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
-    constexpr uint32_t unit_blocks = 8u * FrameCfg<T>::kStepBlocks;          // 6144 blocks: eight super-steps, 24 groups of 256
-    static_assert(unit_blocks % kTileBlocks == 0, "units start on index groups");
+    // Unit size: whole super-steps (a multiple of 256 blocks: units start on index groups), 8 .. 32 of them, such that the stack's
+    // units come out as whole rounds of the workgroups the GPU holds at once -- 128 x 2048^2 u16 frames: 57 units of 6144 blocks per
+    // frame are 3.6 rounds, the last one 0.55 full, and every unit pays a super-step of pipeline fill; 16 units of 22 272 blocks are
+    // one round (the 512 x 512 stack's shape: one workgroup per 21 846-block frame).
+    constexpr uint32_t step = FrameCfg<T>::kStepBlocks;
+    static_assert(step % kTileBlocks == 0, "units start on index groups");
+    // (a round = what is resident at once, less a margin: 2048 units on 2048 slots ran as two rounds -- 345 us for 128 x 2048^2 u16
+    // frames, the time of four rounds of quarter-size units; 1920 units: one)
+    const uint64_t resident = (uint64_t)(sizeof(T) == 4 ? 6 : 8) * 256u * 15u / 16u;
+    uint32_t unit_blocks = 8u * step;
+    uint64_t best = ~0ull;
+    for (uint32_t k = 8; k <= 32; ++k) {
+        const uint64_t u = (uint64_t)k * step, units = (uint64_t)a.n_frames * ((a.geom.n_blocks + u - 1) / u);
+        const uint64_t cost = ((units + resident - 1) / resident) * (u + step);
+        if (cost < best) { best = cost; unit_blocks = (uint32_t)u; }
+    }
     const uint32_t upf = (a.geom.n_blocks + unit_blocks - 1u) / unit_blocks;
     hipLaunchKernelGGL((k_decode_units_indexed<T>), dim3(a.n_frames * upf), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), unit_blocks,
@@ -840,6 +854,9 @@ hipError_t launch_index_frames(uint32_t max_w, const DecodeArgs& a, bool clear_s
 
 template <typename T>
 static hipError_t launch_decode_frames_indexed_t(const DecodeArgs& a, const uint32_t* list, hipStream_t st) {
+#ifdef TRPX_IDX_AS_UNITS                                  // (experiment: the units instantiation on whole small frames)
+    if (!list) return launch_decode_units_indexed_t<T>(a, st, nullptr);
+#endif
     hipLaunchKernelGGL((k_decode_frames_indexed<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), list,
                        static_cast<T*>(a.pixels_out), a.status);

@@ -99,8 +99,18 @@ __device__ __forceinline__ PartCk part_ck_load(const PartCk* src) {
     return c;
 }
 
+// Which frames stay whole on the per-frame route (one workgroup per frame; header-dense ones handed to the one-wavefront
+// position-parallel walk): up to kPartMaxBlocks blocks always; in a stack of kManyFrames frames and more up to kManyBlocks -- the
+// workgroups of such a stack fill the GPU by themselves, and cutting its frames costs more than it levels (1280 x 640^2 Poisson(3)
+// frames through the index route: 1.42 ms; 2000 x 512^2, the same bytes: 0.74).
+static uint32_t g_many_frames = kManyFrames, g_many_blocks = kManyBlocks;
+void set_single_part_rule(uint32_t many_frames, uint32_t many_blocks) { g_many_frames = many_frames; g_many_blocks = many_blocks; }
+uint32_t single_part_blocks(size_t n_frames) {
+    return n_frames >= g_many_frames && g_many_blocks > kPartMaxBlocks ? g_many_blocks : kPartMaxBlocks;
+}
+
 uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames) {
-    if (g.n_blocks <= kPartMaxBlocks || n_frames == 0) return 1u;
+    if (g.n_blocks <= single_part_blocks(n_frames) || n_frames == 0) return 1u;
     // enough parts to fill the GPU one and a half times over (8 workgroups per CU), of 4 K .. 16 K blocks
 #ifdef TRPX_DIAGNOSTICS
     static const uint64_t want_total = getenv("TRPX_PART_TOTAL") ? (uint64_t)atoi(getenv("TRPX_PART_TOTAL")) : 3072u;
@@ -973,7 +983,7 @@ constexpr uint32_t kChainEntSlack = 80;
 // stragglers doubled k_chain_walk's time (eight 4096 x 4096 frames, 5464 parts: 146 us; tools/chain_stamps.py) --, of 1 K ..
 // 16 K blocks each; + the tail part.
 uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames) {
-    if (g.n_blocks <= kPartMaxBlocks || n_frames == 0) return 1u;
+    if (g.n_blocks <= single_part_blocks(n_frames) || n_frames == 0) return 1u;
 #ifdef TRPX_DIAGNOSTICS
     static const uint64_t waves = getenv("TRPX_CHAIN_WAVES") ? (uint64_t)atoi(getenv("TRPX_CHAIN_WAVES")) : (uint64_t)TRPX_CHAIN_WAVES;
 #else

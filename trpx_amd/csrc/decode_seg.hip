@@ -998,18 +998,18 @@ __global__ __launch_bounds__(kWave) void k_seg_fallback(const uint8_t* __restric
 // sum and write pass in one launch, which is what the per-frame decoder's deferral needs; larger frames get segments of
 // about kSegTargetBlocks blocks, i.e. enough wavefronts to fill the GPU even for a handful of frames (eight 4096 x 4096
 // frames: 8 x 228 wavefronts; measured walk time for them with targets 320 / 160 / 96 / 64 blocks: 1.17 / 1.03 / 0.87 / 1.08 ms).
-uint32_t seg_waves_per_frame(const FrameGeom& g) {
+uint32_t seg_waves_per_frame(const FrameGeom& g, size_t n_frames) {
 #ifdef TRPX_DIAGNOSTICS
     static const uint64_t kSegTargetBlocks = getenv("TRPX_SEG_TARGET") ? (uint64_t)atoi(getenv("TRPX_SEG_TARGET")) : 96;
 #else
     constexpr uint64_t kSegTargetBlocks = 96;
 #endif
-    if (g.n_blocks <= 32768u) return 1;
+    if (g.n_blocks <= single_part_blocks(n_frames)) return 1;
     const uint64_t k = ((uint64_t)g.n_blocks + 32 * kSegTargetBlocks) / (64 * kSegTargetBlocks);
     return (uint32_t)(k ? k : 1);
 }
 size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames) {
-    const size_t K = seg_waves_per_frame(g), segs = n_frames * K * kWave;
+    const size_t K = seg_waves_per_frame(g, n_frames), segs = n_frames * K * kWave;
     return align_up(segs * (8 + 8 + 4 + 4) + n_frames * K * 12 + n_frames * 4, 256);
 }
 
@@ -1044,7 +1044,7 @@ static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t
 }
 
 hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
-    const uint32_t K = seg_waves_per_frame(a.geom);
+    const uint32_t K = seg_waves_per_frame(a.geom, a.n_frames);
     if (K == 1) {
         const SegWs ws = seg_carve(a.seg_ws, a.n_frames, K);
         hipLaunchKernelGGL(k_seg_frames, dim3(a.n_frames), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
@@ -1058,7 +1058,7 @@ hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st) 
 // The decode index of the frames listed in a.defer: one wavefront per listed frame, or the launches of launch_seg_multi for
 // frames of more than 32 K blocks.
 hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st) {
-    const uint32_t K = seg_waves_per_frame(a.geom);
+    const uint32_t K = seg_waves_per_frame(a.geom, a.n_frames);
     if (K > 1) return launch_seg_multi(a, max_w, K, static_cast<const uint32_t*>(a.defer), st);
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
     hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
@@ -1070,7 +1070,7 @@ template <typename T>
 static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
     const hipError_t e0 = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
     if (e0 != hipSuccess) return e0;
-    if (seg_waves_per_frame(a.geom) > 1u) {                     // large frames: their tiles, spread over the GPU
+    if (seg_waves_per_frame(a.geom, a.n_frames) > 1u) {                     // large frames: their tiles, spread over the GPU
         constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
         const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);
         hipLaunchKernelGGL((k_unpack_listed<T>), dim3((uint32_t)(tiles < 1024 ? tiles : 1024)), dim3(kThreads), 0, st, a.terse,
@@ -1086,7 +1086,7 @@ static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) 
     return hipGetLastError();
 }
 
-bool seg_single_wave(const FrameGeom& g) { return seg_waves_per_frame(g) == 1; }
+bool seg_single_wave(const FrameGeom& g, size_t n_frames) { return seg_waves_per_frame(g, n_frames) == 1; }
 
 // Decodes the frames flagged in a.defer (see k_decode_frames); needs seg_single_wave(a.geom).
 hipError_t launch_decode_deferred(int dtype, const DecodeArgs& a, hipStream_t st) {

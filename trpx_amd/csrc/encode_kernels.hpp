@@ -35,6 +35,14 @@ struct PartDesc {
 };
 constexpr uint32_t kPartBlocks = 16384;            // blocks per part, at most about (parts are cut at bit positions; stacks of few frames get smaller parts)
 constexpr uint32_t kPartMaxBlocks = 32768;         // frames of up to this many blocks are one part; no part may hold more
+// Stacks of kManyFrames frames and more keep frames of up to kManyBlocks blocks whole (single_part_blocks; the per-frame kernels'
+// own limit, 2^26 bits per frame, is checked where the route is chosen).  tools/experiments/route_sweep.sh, ~1 GB of u16 pixels,
+// index route / whole frames: Poisson(3) 1280 x 640^2 1.42 / 0.86 ms, 888 x 768^2 1.13 / 0.96, 960 x (1030 x 1065) 2.20 / 1.68, 500 x
+// 1024^2 1.08 / 1.36, 250 x 1448^2 1.07 / 2.28; synth-v1 0.52 / 0.23, 0.41 / 0.28, 0.87 / 0.73, 0.41 / 0.43, 0.43 / 0.81.
+constexpr uint32_t kManyFrames = 768;
+constexpr uint32_t kManyBlocks = 1u << 20;
+uint32_t single_part_blocks(size_t n_frames);
+void set_single_part_rule(uint32_t many_frames, uint32_t many_blocks);   // ($TRPX_SINGLE_PART = "frames,blocks": tuning runs)
 
 struct DecodeArgs {
     const uint8_t*  terse;         // device
@@ -104,7 +112,7 @@ hipError_t launch_walk_groups(const DecodeArgs& a, uint32_t max_w, const uint64_
 size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 // frames k_decode_frames flagged in a.defer (explicit headers every few blocks): position-parallel walk + tiled extraction
-bool seg_single_wave(const FrameGeom& g);
+bool seg_single_wave(const FrameGeom& g, size_t n_frames);
 hipError_t launch_decode_deferred(int dtype, const DecodeArgs& a, hipStream_t st);
 hipError_t launch_synth(int dtype, uint64_t seed, uint64_t frame0, size_t n_frames, size_t n_values,
                         void* out, hipStream_t st);
