@@ -18,7 +18,7 @@ for c in range(cases):
     n = int(rng.choice([4, 12, 52, 388, 4096, 12 * 768 + 4, 40000, 131072, 262144 + 8 * rng.randint(0, 3), 12 * 34000 + 8 * rng.randint(0, 3),
                         513 * 511, 12 * 70000 + rng.randint(0, 12), 1030 * 1065, 1030 * 1065, 1475 * 1679, 2048 * 2048 + rng.randint(0, 3)]))   # (> 32768 blocks: cut into parts, decode_part.hip)
     n = max(1, n - rng.randint(0, 4) * rng.randint(0, 2))                                     # (half of the cases: no multiple of 4)
-    frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else (int(rng.choice([1, 3, 130])) if n <= 12 * 34000 + 16 else int(rng.choice([1, 2, 9])))
+    frames = int(rng.choice([1, 2, 3, 17, 129, 140])) if n <= 40000 else (int(rng.choice([1, 3, 130, 130, 130, 800])) if n <= 12 * 34000 + 16 else int(rng.choice([1, 2, 9])))
     nblk = (n + 11) // 12
     kind = rng.randint(8)
     if kind == 0:   hi = np.full((frames, nblk), rng.randint(0, top + 1))                    # one width

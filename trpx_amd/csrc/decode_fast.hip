@@ -168,6 +168,15 @@ static hipError_t launch_decode_fast_t(const DecodeArgs& a, bool have_index, boo
         prof.mark(st);
         return e;
     }
+#ifndef TRPX_INDEXED_LARGE_TILES
+    if (have_index && sizeof(T) < 4 && g.n_blocks >= (1u << 18) &&
+        8 * (uint64_t)g.n_blocks * (12u + 12u * max_w) < (1ull << 31)) {   // large frames of 8/16-bit pixels with their index: units of the per-frame decoder, as the index route extracts them (decode_frame.hip)
+        constexpr int dtype = PixelTraits<T>::bits == 8 ? (PixelTraits<T>::is_signed ? 1 : 0) : (PixelTraits<T>::is_signed ? 3 : 2);
+        const hipError_t e = launch_decode_units_indexed(dtype, a, st, nullptr);
+        prof.mark(st);
+        return e;
+    }
+#endif
     hipLaunchKernelGGL((k_unpack_tiles<T>), dim3((uint32_t)((uint64_t)a.n_frames * tpf)), dim3(kThreads), 0, st, a.terse,
                        (uint64_t)a.terse_bytes, a.frame_offsets, g, tpf, a.widths, a.tile_off,
                        static_cast<T*>(a.pixels_out), a.status, static_cast<const uint32_t*>(nullptr));
