@@ -298,6 +298,8 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
                     // stream through its LDS window for the same effect; without it the extraction's requests queue up between
                     // the texture-address unit and the vector cache whenever HBM answers late: the kernel's slow state,
                     // profiles/r04_idx_gap.txt.)  The value is never used; the register is given up at the next super-step.
+                    // (Touching the next super-step's expected span as well, a super-step further ahead: no different.  Line images
+                    // for frames that start inside a cache line, as MODE 0 writes them: 0.351 against 0.33 ms, again.)
                     const uint64_t a0 = (4u * frame_dw + ((frame_sh + pos_begin) >> 3)) & ~127ull;
                     const uint64_t a1 = 4u * frame_dw + ((frame_sh + (pos <= limit ? pos : limit)) >> 3);
                     for (uint64_t my = a0 + 128u * lane; my <= a1 && my + 4u <= terse_bytes; my += 128u * kWave)
@@ -775,7 +777,11 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
         if (blockIdx.x >= list[0] || status[0] != 0u) return;
         frame = list[1u + blockIdx.x] & 0x7FFFFFFFu;
     }
+#ifdef TRPX_IDX_LINES                                     // (experiment: line images in the indexed kernel, as k_decode_frames<T, true> writes them)
+    decode_frame_body<T, 1, false, true>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
+#else
     decode_frame_body<T, 1>(terse, terse_bytes, frame_offsets, g, pixels_out, nullptr, status, frame, widths, group_off);
+#endif
 }
 
 // Large frames whose index is known, in units of `unit_blocks` blocks (a multiple of 256 and of a super-step): the same body, one
