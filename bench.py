@@ -35,7 +35,7 @@ ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
 PROFILE_TAG = "r05"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
 DEC_STAGES_FRAMES = ["decode_frames", "deferred_frames"]  # one workgroup per frame (walk + extraction fused) + the frames it defers
 # frames of more than 32 K blocks (decode_part.hip, the index route): the one walk of short parts up to the part table / decode index
-# (k_chain_guess, k_chain_walk, k_chain_repair, k_chain_resolve, k_chain_index), then the other route's launch for listed frames
+# (k_chain_walk -- start states, walk and links in one launch --, k_chain_resolve, k_chain_index), then the other route's launch for listed frames
 # (k_seg_fallback, normally empty) + the extraction (k_unpack_tiles / k_decode_units_indexed / k_decode_parts)
 DEC_STAGES_LARGE = ["chain_walk_to_index", "fallback_and_extract"]
 
