@@ -798,16 +798,30 @@ __global__ __launch_bounds__(kFrameThreads, sizeof(T) == 4 ? 6 : 8) void k_decod
                                   reinterpret_cast<const PartDesc*>((uintptr_t)unit_blocks));
 }
 template <typename T>
+static uint32_t units_choose(const DecodeArgs& a, uint64_t* cost_out);
+template <typename T>
 static hipError_t launch_decode_units_indexed_t(const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
     // Unit size: whole super-steps (a multiple of 256 blocks: units start on index groups), 8 .. 32 of them, such that the stack's
     // units come out as whole rounds of the workgroups the GPU holds at once -- 128 x 2048^2 u16 frames: 57 units of 6144 blocks per
     // frame are 3.6 rounds, the last one 0.55 full, and every unit pays a super-step of pipeline fill; 16 units of 22 272 blocks are
     // one round (the 512 x 512 stack's shape: one workgroup per 21 846-block frame).
+    const uint32_t unit_blocks = units_choose<T>(a, nullptr);
+    const uint32_t upf = (a.geom.n_blocks + unit_blocks - 1u) / unit_blocks;
+    hipLaunchKernelGGL((k_decode_units_indexed<T>), dim3(a.n_frames * upf), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+                       a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), unit_blocks,
+                       static_cast<T*>(a.pixels_out), a.status, frame_mode);
+    return hipGetLastError();
+}
+// (cost: rounds of resident workgroups x (blocks per unit + a super-step of pipeline fill); a round = what is resident at once --
+// a stack of 2128 frames of 480 x 512 pixels decodes whole in two rounds, the second one 4 % full: 0.267 ms against 0.230 for 2000
+// frames of 512 x 512, the same bytes)
+constexpr uint64_t units_resident(size_t pixel_bytes) { return (uint64_t)(pixel_bytes == 4 ? 6 : 8) * 256u; }
+template <typename T>
+static uint32_t units_choose(const DecodeArgs& a, uint64_t* cost_out) {
     constexpr uint32_t step = FrameCfg<T>::kStepBlocks;
     static_assert(step % kTileBlocks == 0, "units start on index groups");
-    // (a round = what is resident at once, less a margin: 2048 units on 2048 slots ran as two rounds -- 345 us for 128 x 2048^2 u16
-    // frames, the time of four rounds of quarter-size units; 1920 units: one)
-    const uint64_t resident = (uint64_t)(sizeof(T) == 4 ? 6 : 8) * 256u * 15u / 16u;
+    // (less a margin: 2048 units on 2048 slots ran as two rounds)
+    const uint64_t resident = units_resident(sizeof(T)) * 15u / 16u;
     uint32_t unit_blocks = 8u * step;
     uint64_t best = ~0ull;
     for (uint32_t k = 8; k <= 32; ++k) {
@@ -815,11 +829,8 @@ static hipError_t launch_decode_units_indexed_t(const DecodeArgs& a, hipStream_t
         const uint64_t cost = ((units + resident - 1) / resident) * (u + step);
         if (cost < best) { best = cost; unit_blocks = (uint32_t)u; }
     }
-    const uint32_t upf = (a.geom.n_blocks + unit_blocks - 1u) / unit_blocks;
-    hipLaunchKernelGGL((k_decode_units_indexed<T>), dim3(a.n_frames * upf), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
-                       a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), unit_blocks,
-                       static_cast<T*>(a.pixels_out), a.status, frame_mode);
-    return hipGetLastError();
+    if (cost_out) *cost_out = best;
+    return unit_blocks;
 }
 hipError_t launch_decode_units_indexed(int dtype, const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode) {
     switch (dtype) {
@@ -863,6 +874,15 @@ static hipError_t launch_decode_frames_indexed_t(const DecodeArgs& a, const uint
 #ifdef TRPX_IDX_AS_UNITS                                  // (experiment: the units instantiation on whole small frames)
     if (!list) return launch_decode_units_indexed_t<T>(a, st, nullptr);
 #endif
+    if (!list && a.geom.n_blocks > 8u * FrameCfg<T>::kStepBlocks) {
+        // A frame count a little over a multiple of what the GPU holds leaves the last round of whole frames nearly empty: units of
+        // the frames -- the same body -- where their rounds come out at least a tenth cheaper.
+        uint64_t cost_units = 0;
+        units_choose<T>(a, &cost_units);
+        const uint64_t resident = units_resident(sizeof(T));
+        const uint64_t cost_whole = ((a.n_frames + resident - 1) / resident) * ((uint64_t)a.geom.n_blocks + FrameCfg<T>::kStepBlocks);
+        if (10u * cost_units < 9u * cost_whole) return launch_decode_units_indexed_t<T>(a, st, nullptr);
+    }
     hipLaunchKernelGGL((k_decode_frames_indexed<T>), dim3(a.n_frames), dim3(kFrameThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, static_cast<const uint8_t*>(a.widths), static_cast<const uint64_t*>(a.tile_off), list,
                        static_cast<T*>(a.pixels_out), a.status);
