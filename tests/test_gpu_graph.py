@@ -48,6 +48,47 @@ def test_encode_decode_capture_into_hip_graph(gpu):
     assert torch.equal(back.view(torch.int16), px.view(torch.int16))
 
 
+def test_large_frame_decode_replays_from_a_hip_graph(gpu):
+    """The large-frame route's walk is one launch whose wavefronts wait for each other's words (decode_part.hip, k_chain_walk);
+    the words are cleared by the call's first launch (k_chain_zero), so a captured decode replays like an eager one: replayed
+    three times over new pixels each time -- 1030 x 1065 frames (parts extracted by the per-frame decoder), Poisson(3) counts of
+    the same size (the index route's extraction) -- and compared with the pixels."""
+    import torch
+    from trpx_amd import codec, _lib, workloads
+    n, frames = 1030 * 1065, 6
+    L = _lib.lib()
+    assert L.trpx_decode_parts_per_frame(_lib.U16, n, frames, 12) > 3
+    ws_e, ws_d = codec.Workspace(gpu), codec.Workspace(gpu)
+    ws_e.get(L.trpx_encode_workspace_bytes(_lib.U16, n, frames, 12))
+    ws_d.get(L.trpx_decode_workspace_bytes(_lib.U16, n, frames, 12))
+    cap = (frames * codec.worst_case_bytes(np.uint16, n) + 15) // 16 * 16
+    out = torch.empty(cap, dtype=torch.uint8, device=gpu)
+    offs = torch.empty(frames + 1, dtype=torch.int64, device=gpu)
+    st_e = torch.empty(8, dtype=torch.int32, device=gpu)
+    st_d = torch.empty(8, dtype=torch.int32, device=gpu)
+    px = codec.synth(np.uint16, 0, frames, n, device=gpu)
+    back = torch.empty_like(px)
+    codec.encode(px, out=out, workspace=ws_e, frame_offsets=offs, status=st_e)           # (eager warm-up: the encoder's workspace is known clean)
+    codec.decode(out, offs, n, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
+    torch.cuda.synchronize()
+    assert torch.equal(back, px)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            codec.encode(px, out=out, workspace=ws_e, frame_offsets=offs, status=st_e)
+            codec.decode(out, offs, n, frames, np.uint16, out=back, workspace=ws_d, status=st_d)
+    for k, make in enumerate((lambda: codec.synth(np.uint16, 100, frames, n, device=gpu),
+                              lambda: workloads.poisson_u16(3.0, 7, frames, n, device=gpu),
+                              lambda: codec.synth(np.uint16, 300, frames, n, device=gpu))):
+        px.copy_(make())
+        back.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(st_e[0].item()) == 0 and int(st_d[0].item()) == 0, k
+        assert torch.equal(back, px), k
+
+
 def test_eager_and_replayed_encodes_alternate_on_one_workspace(gpu, oracle):
     """A captured call bakes its arguments in; the library's memory of clean workspaces is only updated by eager calls
     (encode_fused.hip: launch_fused_t).  Capture -> eager -> replay -> eager -> replay -> eager on ONE workspace: every call
