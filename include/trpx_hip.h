@@ -227,7 +227,11 @@ int trpx_set_encode_path(int path);
  * it from 1024 frames on, then uses it for any number).  Every route yields the same pixels (Terse.hpp:352-389); the
  * setter exists for tests and A/B measurements.
  * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames|parts.
- * These two variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
+ * Frames of more than 32 K blocks are cut into parts (one walk of many short parts, then extraction through the decode
+ * index it yields) unless the stack holds 768 frames or more, which keep them whole on the per-frame decoder -- such a
+ * stack fills the GPU by itself; TRPX_SINGLE_PART=<frames>,<blocks> moves that line for tuning runs (stacks of <frames>
+ * frames and more keep frames of up to <blocks> blocks whole).
+ * These three variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
  * The tuned kernels issue 8- and 16-byte accesses at addresses that are only aligned to the pixel type (frames of any
  * pixel count): they rely on the HSA unaligned-access mode, which ROCm enables on gfx950.
  */
