@@ -409,7 +409,7 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
     // costs its repair a whole part's walk (71 of 4200 parts stopped: the repair launch 236 instead of ~20 us).
     // (32-bit pixels: from 24 on -- their parts hold half the blocks per bit, a stopped part's repair is a short walk (65 us for
     // eight 4096^2 frames' parts, where two walks that kept starting again for 100 Kbits made k_chain_walk 187 instead of ~100 us))
-#ifdef TRPX_PART_STATS
+#ifdef TRPX_GUESS_STATS    // (not part of TRPX_PART_STATS: a printf in front of the start state's publication holds up every wavefront that waits for it -- hundreds ran into the diagnostic build's 30 s bound)
     if (lane == 0 && (X & 0xFFu) < 24u) printf("guess: no run behind %u: best width %u depth %u, most12 %u, passes %u, max_w %u, limit %u reach %u\n", X, best_w, best_d, most12, passes, max_w, limit, reach);
 #endif
     return most12 >= (max_w > 16u ? 24u : 40u) ? PartState{X, kPartWeak | kPartRuns} : plain;
