@@ -97,20 +97,20 @@ int g_decode_path = [] {
     return 0;
 }();
 struct IdxLayout { size_t group_off, widths, seg, defer, parts, part_ws, total; };
-IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames) {
+IdxLayout idx_layout(const trpx::FrameGeom& g, size_t n_frames, size_t pixel_bytes = 4) {   // (pixel_bytes: only the scratch behind the index proper depends on it)
     IdxLayout l;
     l.group_off = 0;
     l.widths = trpx::align_up(8 * n_frames * (size_t)g.n_tiles, 16);
     l.seg = trpx::align_up(l.widths + n_frames * (size_t)g.n_blocks, 256);   // scratch of trpx_build_index's walk
     l.defer = l.seg + trpx::seg_workspace_bytes(g, n_frames);                 // list of the frames the per-frame walker hands over
     l.parts = l.defer + trpx::defer_bytes(n_frames);                          // large frames: the index route's part table and scratch (decode_part.hip)
-    const size_t P = trpx::chain_parts_per_frame(g, n_frames);
+    const size_t P = trpx::chain_parts_per_frame(g, n_frames, pixel_bytes);
     l.part_ws = l.parts + (P > 1 ? trpx::align_up(sizeof(trpx::PartDesc) * n_frames * P, 256) : 0);
-    l.total = l.part_ws + trpx::chain_workspace_bytes(g, n_frames);
+    l.total = l.part_ws + trpx::chain_workspace_bytes(g, n_frames, pixel_bytes);
     return l;
 }
 struct DecWs { size_t walk_offsets, tile_off, widths, seg, defer, parts, part_ws, total; };
-DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
+DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames, size_t pixel_bytes) {
     DecWs w;
     const size_t tiles = n_frames * (size_t)g.n_tiles;
     w.walk_offsets = 0;
@@ -120,9 +120,9 @@ DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames) {
     w.defer = w.seg + trpx::seg_workspace_bytes(g, n_frames);
     w.parts = w.defer + trpx::defer_bytes(n_frames);                            // large frames on the per-frame route: the part table
     // (two routes for large frames share these two areas: the index route -- many short parts -- and round 4's parts route)
-    const size_t P = std::max<size_t>(trpx::parts_per_frame(g, n_frames), trpx::chain_parts_per_frame(g, n_frames));
+    const size_t P = std::max<size_t>(trpx::parts_per_frame(g, n_frames), trpx::chain_parts_per_frame(g, n_frames, pixel_bytes));
     w.part_ws = w.parts + (P > 1 ? trpx::align_up(sizeof(trpx::PartDesc) * n_frames * P, 256) : 0);
-    w.total = w.part_ws + std::max(trpx::part_workspace_bytes(g, n_frames), trpx::chain_workspace_bytes(g, n_frames));
+    w.total = w.part_ws + std::max(trpx::part_workspace_bytes(g, n_frames), trpx::chain_workspace_bytes(g, n_frames, pixel_bytes));
     return w;
 }
 
@@ -166,14 +166,14 @@ size_t trpx_encode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, 
 size_t trpx_decode_workspace_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g)) return 0;
-    return dec_ws(g, n_frames).total;
+    return dec_ws(g, n_frames, trpx_dtype_size(dtype)).total;
 }
 
 unsigned trpx_decode_parts_per_frame(int dtype, size_t n_values, size_t n_frames, unsigned block) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(dtype) || is64(dtype) || block != (unsigned)trpx::kBlock || !geom_of(n_values, block, &g)) return 1;
     const bool bits32 = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) < 0xF0000000ull;
-    return g_decode_path != 4 && bits32 ? trpx::chain_parts_per_frame(g, n_frames) : trpx::parts_per_frame(g, n_frames);
+    return g_decode_path != 4 && bits32 ? trpx::chain_parts_per_frame(g, n_frames, trpx_dtype_size(dtype)) : trpx::parts_per_frame(g, n_frames);
 }
 
 static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes, const uint64_t* frame_offsets,
@@ -183,7 +183,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
 size_t trpx_index_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block) {
     trpx::FrameGeom g;
     if (!trpx_dtype_size(dtype) || !geom_of(n_values, block, &g)) return 0;
-    return idx_layout(g, n_frames).total;
+    return idx_layout(g, n_frames, trpx_dtype_size(dtype)).total;
 }
 
 int trpx_encode(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block, uint8_t* out,
@@ -224,7 +224,7 @@ int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n
     a.tile_off = reinterpret_cast<uint64_t*>(ws + w.tile_off);
     a.tile_bits = reinterpret_cast<uint32_t*>(ws + w.tile_bits);
     if ((uintptr_t)index % 16) return fail(TRPX_ERR_INVALID_ARG, "trpx_encode_indexed: index must be 16-byte aligned");
-    const IdxLayout il = idx_layout(g, n_frames);
+    const IdxLayout il = idx_layout(g, n_frames, trpx_dtype_size(dtype));
     a.idx_group_off = index ? reinterpret_cast<uint64_t*>(static_cast<char*>(index) + il.group_off) : nullptr;
     a.idx_widths = index ? reinterpret_cast<uint8_t*>(static_cast<char*>(index) + il.widths) : nullptr;
     if (block != (unsigned)trpx::kBlock || is64(dtype)) {  // any other block size, 64-bit containers: generic (correct-first) kernels
@@ -286,7 +286,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8 ||
         (uintptr_t)pixels_out % trpx_dtype_size(out_dtype))
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode: misaligned pointer (terse needs 4 B, workspace 8 B)");
-    const DecWs w = dec_ws(g, n_frames);
+    const DecWs w = dec_ws(g, n_frames, trpx_dtype_size(out_dtype));
     if (workspace_bytes < w.total)
         return fail(TRPX_ERR_CAPACITY, "trpx_decode: workspace %zu < %zu", workspace_bytes, w.total);
 
@@ -323,7 +323,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     // larger frames, or frames of more than 32 K blocks: cut into parts of the size of a 512 x 512 frame first (decode_part.hip);
     // a part's positions are relative to its own first bit, so the 2^26 limit applies to the part
     a.chain = route != 4 && bits32;                                            // (frame-relative 32-bit positions)
-    a.parts_per_frame = a.chain ? trpx::chain_parts_per_frame(g, n_frames) : trpx::parts_per_frame(g, n_frames);
+    a.parts_per_frame = a.chain ? trpx::chain_parts_per_frame(g, n_frames, trpx_dtype_size(out_dtype)) : trpx::parts_per_frame(g, n_frames);
     const bool parts_ok = a.parts_per_frame > 1u && n_frames * (uint64_t)a.parts_per_frame < 0x7FFFFFFFull && a.defer;
     if (parts_ok) {
         a.parts = reinterpret_cast<trpx::PartDesc*>(ws + w.parts);
@@ -351,7 +351,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
         return fail(TRPX_ERR_INVALID_ARG, "trpx_build_index: misaligned pointer");
     if (8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) >= 0xF0000000ull)
         return fail(TRPX_ERR_UNSUPPORTED, "trpx_build_index: frames of >= 2^32 bits");
-    const IdxLayout il = idx_layout(g, n_frames);
+    const IdxLayout il = idx_layout(g, n_frames, trpx_dtype_size(dtype));
     trpx::DecodeArgs a{};
     a.terse = terse;
     a.terse_bytes = terse_bytes;
@@ -366,7 +366,7 @@ static int build_index_impl(int dtype, const uint8_t* terse, size_t terse_bytes,
     // frames of < 2^26 bits: the per-frame decoder's walker writes the index (the conditions of trpx_decode's per-frame route)
     a.index_per_frame = 8 * (uint64_t)trpx_worst_case_bytes(dtype, n_values, block) + (1u << 17) < (1ull << 26) && g_decode_path != 2;
     // frames of more than 32 K blocks: the index route's one walk of many short parts (decode_part.hip), unless the tiled route is forced
-    a.parts_per_frame = trpx::chain_parts_per_frame(g, n_frames);
+    a.parts_per_frame = trpx::chain_parts_per_frame(g, n_frames, trpx_dtype_size(dtype));
     a.chain = a.parts_per_frame > 1u && n_frames * (uint64_t)a.parts_per_frame < 0x7FFFFFFFull && g_decode_path != 2 && g_decode_path != 4;
     if (a.chain) {
         a.parts = reinterpret_cast<trpx::PartDesc*>(static_cast<char*>(index) + il.parts);
@@ -397,7 +397,7 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     if ((uintptr_t)terse % 4 || (uintptr_t)index % 16 || (uintptr_t)frame_offsets % 8 ||
         (uintptr_t)pixels_out % trpx_dtype_size(out_dtype) || (uintptr_t)status % 8)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_indexed: misaligned pointer (terse needs 4 B, index 16 B)");
-    const IdxLayout il = idx_layout(g, n_frames);
+    const IdxLayout il = idx_layout(g, n_frames, trpx_dtype_size(out_dtype));
     trpx::DecodeArgs a{};
     a.terse = terse;
     a.terse_bytes = terse_bytes;
@@ -478,7 +478,7 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
     if ((uintptr_t)terse % 4 || (uintptr_t)workspace % 8 || (uintptr_t)frame_offsets % 8 || (uintptr_t)status % 8 ||
         (uintptr_t)pixels_out % es)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_decode_convert: misaligned pointer");
-    const DecWs w = dec_ws(g, n_frames);
+    const DecWs w = dec_ws(g, n_frames, es);
     if (workspace_bytes < w.total) return fail(TRPX_ERR_CAPACITY, "trpx_decode_convert: workspace %zu < %zu", workspace_bytes, w.total);
     trpx::fused_ws_forget(workspace, workspace_bytes);
     trpx::DecodeArgs a{};
@@ -720,7 +720,7 @@ int trpx_frame_offsets_host(const uint8_t* terse, size_t terse_bytes, size_t n_v
                     "trpx_frame_offsets_host: unsupported sizes/block (block=%u)", block);
     if (!sizes_ok(g, n_frames) || n_frames > terse_bytes)                     // every frame is at least one byte (Terse.hpp:547)
         return fail(TRPX_ERR_INVALID_ARG, "trpx_frame_offsets_host: bad sizes n_values=%zu n_frames=%zu", n_values, n_frames);
-    const DecWs w = dec_ws(g, n_frames);
+    const DecWs w = dec_ws(g, n_frames, 4);
     struct { void* p = nullptr; } d_in, d_st, d_ws;
     Arena& A = arena();
     hipStream_t hs = nullptr;

@@ -974,6 +974,9 @@ hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t s
 #ifndef TRPX_CHAIN_WAVES
 #define TRPX_CHAIN_WAVES 4352
 #endif
+#ifndef TRPX_CHAIN_WAVES_NARROW
+#define TRPX_CHAIN_WAVES_NARROW 4096
+#endif
 constexpr uint32_t kChainCk = 64;              // checkpoints per part
 constexpr uint32_t kChainTail = 2048;          // bits of the frame's last part (walked by count in k_chain_index)
 constexpr uint32_t kChainPatience = 8192;      // bits into a part after which a walk that reads an illegal width stops instead of starting again
@@ -982,12 +985,16 @@ constexpr uint32_t kChainEntSlack = 80;
 // Parts per frame: as many walkers as the GPU holds at once (8 KB of LDS each: 19 per CU) -- a second round of a few hundred
 // stragglers doubled k_chain_walk's time (eight 4096 x 4096 frames, 5464 parts: 146 us; tools/chain_stamps.py) --, of 1 K ..
 // 16 K blocks each; + the tail part.
-uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames) {
+uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames, size_t pixel_bytes) {
     if (g.n_blocks <= single_part_blocks(n_frames) || n_frames == 0) return 1u;
+    // (8 / 16-bit pixels: 4096 -- the parts are also the units k_decode_parts extracts, eight workgroups per CU: two whole rounds
+    // of them instead of two and a tenth; 200 x (1030 x 1065) 0.202 -> 0.193 ms, 128 x 2048^2 0.43 -> 0.405, Poisson(3) mid-size
+    // 0.559 -> 0.537; the int32 frames, extracted by tiles, lose 6 % to the longer parts: 0.3105 -> 0.331)
 #ifdef TRPX_DIAGNOSTICS
-    static const uint64_t waves = getenv("TRPX_CHAIN_WAVES") ? (uint64_t)atoi(getenv("TRPX_CHAIN_WAVES")) : (uint64_t)TRPX_CHAIN_WAVES;
+    static const uint64_t waves_env = getenv("TRPX_CHAIN_WAVES") ? (uint64_t)atoi(getenv("TRPX_CHAIN_WAVES")) : 0u;
+    const uint64_t waves = waves_env ? waves_env : (pixel_bytes < 4 ? (uint64_t)TRPX_CHAIN_WAVES_NARROW : (uint64_t)TRPX_CHAIN_WAVES);
 #else
-    constexpr uint64_t waves = TRPX_CHAIN_WAVES;
+    const uint64_t waves = pixel_bytes < 4 ? (uint64_t)TRPX_CHAIN_WAVES_NARROW : (uint64_t)TRPX_CHAIN_WAVES;
 #endif
     const uint64_t lo = ((uint64_t)g.n_blocks + kPartBlocks - 1u) / kPartBlocks, hi = (uint64_t)g.n_blocks / 1024u;
     uint64_t n = waves / n_frames;
@@ -1015,8 +1022,8 @@ static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     w.total = align_up(w.modes + 4 * n_frames, 256);
     return w;
 }
-size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames) {
-    const size_t P = chain_parts_per_frame(g, n_frames);
+size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames, size_t pixel_bytes) {
+    const size_t P = chain_parts_per_frame(g, n_frames, pixel_bytes);
     return P > 1 ? chain_ws_layout(g, n_frames, P).total : 0;
 }
 

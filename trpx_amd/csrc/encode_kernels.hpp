@@ -71,8 +71,8 @@ size_t part_workspace_bytes(const FrameGeom& g, size_t n_frames);
 hipError_t launch_build_parts(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 // decode_part.hip, the index route: a.widths / a.tile_off of every large frame from ONE walk of many short parts; frames where
 // that does not work out are listed in a.defer (the position-parallel walk writes their index: launch_seg_listed)
-uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames);
-size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames);
+uint32_t chain_parts_per_frame(const FrameGeom& g, size_t n_frames, size_t pixel_bytes);   // (pixel_bytes: of the type decoded into)
+size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames, size_t pixel_bytes);
 // narrow: 8 / 16-bit pixels -- frames with few explicit headers are left to k_decode_parts on a.parts (*frame_mode: per frame, 1 = the
 // index was written, 0 = extract part by part)
 hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool narrow, const uint32_t** frame_mode, hipStream_t st);
