@@ -109,7 +109,12 @@ hipError_t launch_walk_serial(const DecodeArgs& a, uint32_t max_w, hipStream_t s
 hipError_t launch_index_group_states(const DecodeArgs& a, uint64_t* states, hipStream_t st);
 hipError_t launch_walk_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, bool clear_status, hipStream_t st);
 // position-parallel header walk (decode_seg.hip): fills a.widths / a.tile_off like launch_walk_only; needs a.seg_ws
-size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames);
+size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames);   // (includes dense_workspace_bytes(): the listed frames' walk, decode_dense.hip)
+// decode_dense.hip: the decode index of the frames in `list` (frames of up to single_part_blocks() blocks) -- one speculative pass,
+// link walks, a write pass per frame; dense_ws: dense_workspace_bytes()
+size_t dense_workspace_bytes(const FrameGeom& g, size_t n_frames);
+hipError_t launch_dense_listed(const DecodeArgs& a, uint32_t max_w, void* dense_ws, const uint32_t* list, hipStream_t st);
+void set_dense_route(bool on);                                       // (off: the fix-point rounds of decode_seg.hip, A/B and tests)
 hipError_t launch_seg_walk(const DecodeArgs& a, uint32_t max_w, hipStream_t st);
 // frames k_decode_frames flagged in a.defer (explicit headers every few blocks): position-parallel walk + tiled extraction
 bool seg_single_wave(const FrameGeom& g, size_t n_frames);
