@@ -224,9 +224,11 @@ int trpx_set_encode_path(int path);
  * type only --, the position-parallel walk + tiled extraction for larger frames, the basic kernels for other block
  * sizes and missing frame offsets), 1 = always the basic kernels, 2 = the tiled route whenever its preconditions hold,
  * 3 = the per-frame decoder whenever its preconditions hold (= auto for trpx_decode; trpx_decode_indexed, which takes
- * it from 1024 frames on, then uses it for any number).  Every route yields the same pixels (Terse.hpp:352-389); the
- * setter exists for tests and A/B measurements.
- * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames|parts.
+ * it from 1024 frames on, then uses it for any number), 4 = large frames by round 4's parts route, 5 = auto with the
+ * header-dense frames the per-frame decoder hands over walked by the dense walk (decode_dense.hip: one speculative pass,
+ * link walks, a verified write pass) instead of the fix-point rounds of decode_seg.hip.  Every route yields the same
+ * pixels (Terse.hpp:352-389); the setter exists for tests and A/B measurements.
+ * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames|parts|dense.
  * Frames of more than 32 K blocks are cut into parts (one walk of many short parts, then extraction through the decode
  * index it yields) unless the stack holds 768 frames or more, which keep them whole on the per-frame decoder -- such a
  * stack fills the GPU by itself; TRPX_SINGLE_PART=<frames>,<blocks> moves that line for tuning runs (stacks of <frames>

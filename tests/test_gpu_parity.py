@@ -1092,7 +1092,7 @@ def test_config5_16000_frame_stream_in_eight_shards(gpu, oracle):
 
 
 # ---- the decode route matrix: every route x every pixel type on the fuzz generator ---------------------
-_ROUTES = {"basic": 1, "tiles": 2, "frames": 3, "parts": 4}   # (4: large frames by round 4's parts route instead of the index route; = auto for small frames)
+_ROUTES = {"basic": 1, "tiles": 2, "frames": 3, "parts": 4, "dense": 5}   # (4: large frames by round 4's parts route instead of the index route; = auto for small frames; 5: auto with the listed frames' index by the dense walk, decode_dense.hip)
 
 
 def _fuzz_stack(rng, dt, kind, n, frames):
@@ -1401,6 +1401,56 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_dense_walk_last_resort_and_stress(gpu, oracle, tmp_path):
+    """The dense walk of listed frames (decode_dense.hip, route 5) in two test builds.  `denseserial` (-DTRPX_DENSE_FORCE_SERIAL):
+    every listed frame skips its write pass and is walked by one lane from (0, 0) -- the last resort a frame takes when its
+    speculative walks do not close.  `densetiny` (-DTRPX_DENSE_SEG_BLOCKS=1): regions of a few blocks, so that link walks cross
+    dozens of regions, deep records collide and the write pass's checks (end state AND block count of every region) have to
+    catch what the records got wrong -- most frames end in the serial walk, none may be wrong.  status[2] counts those frames."""
+    script = tmp_path / "t.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from trpx_amd import codec, _lib, workloads
+_lib.lib().trpx_set_decode_path(5)
+want_serial = sys.argv[1] == "all"
+rng = np.random.RandomState(11)
+total = 0
+hits = []
+for dtype, n, frames in ((np.uint16, 512 * 512, 9), (np.int8, 3000, 140), (np.uint16, 3000, 140), (np.int32, 40000, 6), (np.uint8, 12 * 300 + 7, 130)):
+    dt = np.dtype(dtype)
+    if dtype == np.uint16 and n == 512 * 512:
+        px = workloads.poisson_u16(3.0, 0, frames, n, device="cuda")
+    else:
+        nblk = (n + 11) // 12
+        top = 8 * dt.itemsize - (1 if dt.kind == "i" else 0)
+        hi = rng.choice([0, 1, 2, 3, 5, min(9, top), top], size=(frames, nblk), p=[0.1, 0.2, 0.3, 0.2, 0.1, 0.07, 0.03])
+        mag = (rng.rand(frames, nblk * 12) * (2.0 ** np.repeat(hi, 12, axis=1))).astype(np.int64)[:, :n]
+        if dt.kind == "i":
+            mag = np.clip(mag * rng.choice([-1, 1], size=mag.shape), np.iinfo(dt).min, np.iinfo(dt).max)
+        px = torch.from_numpy(mag.astype(dt)).cuda()
+    enc = codec.encode(px, index=True); torch.cuda.synchronize(); enc.check()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dtype)
+    torch.cuda.synchronize()
+    s = st.cpu().numpy()
+    assert s[0] == 0 and torch.equal(back.view(torch.uint8), px.view(torch.uint8)), (dtype, n, frames, s)
+    walked = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, dtype)
+    nb = (n + 11) // 12; ng = (nb + 255) // 256; w_off = (8 * frames * ng + 15) // 16 * 16
+    assert torch.equal(enc.index[: 8 * frames * ng], walked[: 8 * frames * ng]) and torch.equal(enc.index[w_off: w_off + frames * nb], walked[w_off: w_off + frames * nb]), (dtype, n, frames)
+    total += int(s[2])
+    hits.append(int(s[2]))
+assert total > 0 and (not want_serial or sum(1 for h in hits if h > 0) >= 3), hits     # (every LISTED frame of the serial build; which frames are listed is the per-frame decoder's call)
+print("OK", total)
+""")
+    for name, arg in (("denseserial", "all"), ("densetiny", "some")):
+        variant = os.path.join(ROOT, "tools", "variants", f"libtrpx_{name}.so")
+        if not os.path.exists(variant):
+            pytest.skip(f"test variant not built (make -C trpx_amd/csrc {name})")
+        r = subprocess.run([os.sys.executable, str(script), arg], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
+        assert r.returncode == 0 and "OK" in r.stdout, (name, r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_many_large_frames_stay_whole(gpu, oracle):
     """Stacks of 768 frames and more keep frames of more than 32 K blocks on the per-frame route (one workgroup per frame,
     header-dense frames handed to the one-wavefront position-parallel walk) instead of cutting them into parts
@@ -1684,14 +1734,25 @@ def test_large_frames_hostile_streams(gpu, oracle, dtype):
         clean_call_still_works(what)
 
 
-@pytest.mark.parametrize("shape,frames,victim", [((512, 512), 70, 10), ((1030, 1065), 5, 2)])
-def test_header_dense_hostile_streams(gpu, oracle, shape, frames, victim):
+@pytest.mark.parametrize("shape,frames,victim,route", [((512, 512), 70, 10, 0), ((1030, 1065), 5, 2, 0), ((512, 512), 70, 10, 5)])
+def test_header_dense_hostile_streams(gpu, oracle, shape, frames, victim, route):
     """The same for the routes header-dense frames take -- Poisson(3) counts, a width change on one block in four: stacks of
     512 x 512 frames are handed over by the per-frame decoder to the position-parallel walk with one wavefront per frame
     (70 frames: the hand-over is decided by the stack's statistics), frames of 1030 x 1065 fall through the part cuts to the
     walk with several wavefronts per frame (decode_seg.hip).  Both count their blocks from states that are guesses until the
     links close, in passes that do not check widths against the pixel type: a damaged frame must end in TRPX_ERR_CORRUPT or,
-    where only payload bits changed, in status 0 with every other frame exact."""
+    where only payload bits changed, in status 0 with every other frame exact.  route 5: the listed frames through the dense walk
+    (decode_dense.hip: one speculative pass, link walks, a verified write pass, the serial walk as the last resort)."""
+    import torch
+    from trpx_amd import codec, _lib, workloads
+    _lib.lib().trpx_set_decode_path(route)
+    try:
+        _header_dense_hostile(gpu, oracle, shape, frames, victim)
+    finally:
+        _lib.lib().trpx_set_decode_path(0)
+
+
+def _header_dense_hostile(gpu, oracle, shape, frames, victim):
     import torch
     from trpx_amd import codec, _lib, workloads
     n = shape[0] * shape[1]

@@ -50,7 +50,7 @@ def main():
     ok = mode == "enc" or (int(st[0].item()) == 0 and torch.equal(back.view(torch.uint8), px.view(torch.uint8)))
     alg = nf * nv * px.element_size() + enc.total_bytes()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{leg} {mode}: {ms:.4f} ms per call, {alg / ms / 1e6 / 8000:.3f} of 8 TB/s on {alg} algorithmic bytes, exact={ok}, fallback frames={int(st[2].item()) if mode == 'free' else 0}")
+    print(f"{leg} {mode}: {ms:.4f} ms per call, {alg / ms / 1e6 / 8000:.3f} of 8 TB/s on {alg} algorithmic bytes, exact={ok}, fallback frames={int(st[2].item()) if mode == 'free' else 0} status={st.tolist()}")
 
 if __name__ == "__main__":
     main()

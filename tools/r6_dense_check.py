@@ -23,7 +23,7 @@ for dtype in [getattr(np, a) for a in (sys.argv[1:] or ["uint8", "int8", "uint16
         ntiles = (nblk + 255) // 256
         woff = (8 * frames * ntiles + 15) // 16 * 16
         ref = enc.index.cpu().numpy()
-        for route in (0, 5):
+        for route in (5, 0):
             _lib.lib().trpx_set_decode_path(route)
             back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt)
             torch.cuda.synchronize()

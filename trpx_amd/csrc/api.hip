@@ -86,7 +86,7 @@ int g_decode_path = [] {
     const char* e = getenv("TRPX_DECODE_PATH");
     if (!e) return 0;
     return strcmp(e, "basic") == 0 ? 1 : (strcmp(e, "tiles") == 0 || strcmp(e, "seg") == 0) ? 2 : strcmp(e, "frames") == 0 ? 3
-           : strcmp(e, "parts") == 0 ? 4 : strcmp(e, "rounds") == 0 ? (trpx::set_dense_route(false), 0) : 0;
+           : strcmp(e, "parts") == 0 ? 4 : strcmp(e, "dense") == 0 ? (trpx::set_dense_route(true), 0) : 0;
 }();
 // $TRPX_SINGLE_PART = "frames,blocks": stacks of that many frames and more keep frames of up to that many blocks on the per-frame
 // route (encode_kernels.hpp: single_part_blocks; tuning runs -- the built-in rule otherwise)
@@ -510,8 +510,8 @@ int trpx_set_encode_path(int path) {
 }
 
 int trpx_set_decode_path(int path) {
-    if (path < 0 || path > 5) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_decode_path: 0 = auto, 1 = basic, 2 = tiled, 3 = per-frame, 4 = parts route for large frames, 5 = auto with the fix-point rounds for listed frames");
-    trpx::set_dense_route(path != 5);
+    if (path < 0 || path > 5) return fail(TRPX_ERR_INVALID_ARG, "trpx_set_decode_path: 0 = auto, 1 = basic, 2 = tiled, 3 = per-frame, 4 = parts route for large frames, 5 = auto with the dense walk for listed frames");
+    trpx::set_dense_route(path == 5);
     g_decode_path = path == 5 ? 0 : path;
     return TRPX_OK;
 }

@@ -38,7 +38,7 @@
 
 namespace trpx {
 
-constexpr uint32_t kDenseCk = 32;              // checkpoint entries per segment
+constexpr uint32_t kDenseCk = 16;              // checkpoint entries per segment (LDS: 4 bytes each)
 constexpr uint32_t kDenseSlots = 6;            // records per region: depth 1 .. 5, and one for every deeper walk
 constexpr uint32_t kDenseMaxDepth = 24;        // regions a link walk crosses at most
 constexpr uint32_t kStDeep = 6, kStFail = 7;   // states 0 (the lane's own walk) .. 5 = depth; 6 = deeper; 7 = no true walk known
@@ -46,13 +46,18 @@ enum : uint32_t { kRecMerged = 2, kRecThrough = 3, kRecFail = 4 };
 struct DenseRec { uint64_t out; uint32_t cnt, flag; };
 constexpr uint32_t kDenseIdent = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18;
 
+#ifndef TRPX_DENSE_SEG_BLOCKS
+#define TRPX_DENSE_SEG_BLOCKS 330
+#endif
+constexpr uint32_t kDenseSegBlocks = TRPX_DENSE_SEG_BLOCKS;   // blocks per segment, at least about
 uint32_t dense_waves(const FrameGeom& g) {
     // segments of ~170 blocks (a guess chain has merged within its own segment 93 % of the time at 1.5 % per block)
-    return g.n_blocks <= 8192u ? 1u : g.n_blocks <= 49152u ? 2u : g.n_blocks <= 131072u ? 4u : 8u;
+    const uint32_t lanes = g.n_blocks / kDenseSegBlocks;
+    return lanes <= 80u ? 1u : lanes <= 160u ? 2u : 4u;       // (W = 8 would not fit the LDS: 9 KB of windows + 4 KB of checkpoints per wavefront)
 }
 size_t dense_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     const size_t segs = n_frames * 64u * dense_waves(g);
-    return align_up(segs * (kDenseCk * 8u + kDenseSlots * sizeof(DenseRec)), 256);
+    return align_up(segs * (kDenseSlots * sizeof(DenseRec) + 8u), 256);
 }
 
 // first the map A, then B (3 bits per state 0 .. 6; 7 = fail stays fail)
@@ -77,19 +82,94 @@ __device__ __forceinline__ uint32_t dense_scan_tables(uint32_t x) {             
 }
 __device__ __forceinline__ uint32_t dense_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63); }
 
+// A checkpoint: the state in which a lane's walk crosses a window boundary and the blocks it has counted up to there, 4 bytes in
+// LDS (in HBM every 8-byte entry was a partial-line write and a sector fetch: the walk moved twice the bytes of the rounds it
+// replaces) -- position relative to the boundary (a block is at most 396 bits), width, count.  0: none.
+__device__ __forceinline__ uint32_t dense_ck_pack(uint32_t rel, uint32_t w, uint32_t cnt) {
+    return rel < 512u && cnt < (1u << 16) ? 1u | rel << 1 | (w & 63u) << 10 | cnt << 16 : 0u;
+}
+struct DenseSpec {                             // seg_walk's hook of the speculative pass: leaves the checkpoints
+    uint32_t* ck;                              // this lane's kDenseCk entries
+    uint32_t every, X;
+    __device__ __forceinline__ void open(uint32_t, bool) {}
+    __device__ __forceinline__ bool close(uint32_t t, bool act0, uint32_t wend, uint32_t& pos, uint32_t& w, uint32_t& n, bool&, uint32_t&) {
+        if (act0 && pos >= wend) {                                             // crossed the boundary behind window t
+            const uint32_t i = (t + 1u) / every;
+            if (i * every == t + 1u && i < kDenseCk) ck[i] = dense_ck_pack(pos - wend, w, n);
+        }
+        return false;
+    }
+};
+
+// The link walk's bookkeeping (see the head of the file), called by seg_walk when a window closes.
+struct DenseLink {
+    const uint32_t* s_ck;      // the frame's checkpoints (LDS)
+    DenseRec* rec;             // the frame's records
+    const uint64_t* g_out;     // OUT states of the frame's lanes (global: written in front of the workgroup's barrier)
+    const uint32_t *s_cnt, *s_bnd;
+    uint32_t j, jl, n_w, every, limit;
+    bool have;
+    uint32_t s, d, depth, n_entry;
+    uint64_t so;               // the OUT state of the region's own lane (requested when the region is entered)
+    __device__ __forceinline__ uint32_t ck_index(uint32_t t) const {          // entry of region s for the boundary behind this lane's window t; ~0: none
+        if (t + 1u < (s - j) * n_w) return ~0u;                                // (the region starts behind that boundary)
+        const uint32_t b = t + 1u - (s - j) * n_w, i = b / every;             // boundary number inside region s
+        return i * every == b && i < kDenseCk ? i : ~0u;
+    }
+    __device__ __forceinline__ void open(uint32_t, bool) {}
+    // at or behind the region's end: the record, and on into the next region
+    __device__ __forceinline__ void region_end(uint32_t& pos, uint32_t& w, uint32_t& n, bool& done, uint32_t& end) {
+        while (have && (pos >= end || pos > limit)) {
+            DenseRec r;
+            const uint32_t at = s * kDenseSlots + d - 1u;
+            const uint64_t here = seg_pack(pos, w);
+            if (pos > limit) { r = DenseRec{0ull, 0u, kRecFail}; have = false; }                                   // (a chain that left the frame: not the frame's)
+            else {
+                if (here == so) { r = DenseRec{so, n - n_entry, kRecMerged}; have = false; }                       // merged by the region's end
+                else {
+                    r = DenseRec{here, n - n_entry, kRecThrough};
+                    if (s + 1u >= jl) have = false;                                                                 // the last counted region: the tail starts here
+                    else if (++depth > kDenseMaxDepth) { r.flag = kRecFail; have = false; }
+                    else { ++s; d = d < kStDeep ? d + 1u : kStDeep; n_entry = n; end = s_bnd[s + 1u]; so = g_out[s]; }
+                }
+            }
+            rec[at] = r;
+        }
+        done = !have;
+    }
+    __device__ __forceinline__ bool close(uint32_t t, bool act0, uint32_t wend, uint32_t& pos, uint32_t& w, uint32_t& n, bool& done, uint32_t& end) {
+        if (!act0 || !have) return false;
+        region_end(pos, w, n, done, end);
+        if (have && pos >= wend) {                                             // a boundary inside the region: has the chain met the region's own walk?
+            const uint32_t i = ck_index(t);
+            if (i != ~0u) {
+                const uint32_t ck = s_ck[s * kDenseCk + i];
+                if (ck != 0u && (ck & 0xFFFFu) == (dense_ck_pack(pos - wend, w, 0u) & 0xFFFFu)) {
+                    rec[s * kDenseSlots + d - 1u] = DenseRec{so, (n - n_entry) + (s_cnt[s] - (ck >> 16)), kRecMerged};
+                    have = false; done = true;
+                }
+            }
+        }
+        return have && !done && pos < wend;
+    }
+};
+
 #ifdef TRPX_DENSE_STAMPS
-#define TRPX_DENSE_STAMP_PRINT() do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0 && slot % 125u == 0u) printf("dense stamps: slot %u frame %u start %llu spec %u link %u (depths %u) resolve %u write %u (10 ns ticks) jl %u L %u\n", slot, (uint32_t)frame, (unsigned long long)st_t0, (uint32_t)(st_t1 - st_t0), (uint32_t)(st_t2 - st_t1), st_depths, (uint32_t)(st_t3 - st_t2), (uint32_t)(__builtin_amdgcn_s_memrealtime() - st_t3), jl, c.L); } while (0)
+// diagnostic build (tools/r6_variant.sh ... -DTRPX_DENSE_STAMPS): per-frame phase times (10 ns ticks) folded into the status block --
+// [3] max total, [4] max link, [5] sum of link / 16, [6] sum of total / 16, [7] max spec
+#define TRPX_DENSE_STAMP_PRINT() do { if (threadIdx.x == 0) { const uint32_t tot = (uint32_t)(__builtin_amdgcn_s_memrealtime() - st_t0), lnk = (uint32_t)(st_t2 - st_t1); \
+    atomicMax(&status[3], tot); atomicMax(&status[4], lnk); atomicAdd(&status[5], lnk >> 4); atomicAdd(&status[6], tot >> 4); atomicMax(&status[7], (uint32_t)(st_t1 - st_t0)); (void)st_t3; (void)st_depths; } } while (0)
 #endif
 template <uint32_t W>
 __global__ __launch_bounds__(64 * W, 4) void k_dense_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                             const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
-                                                            uint64_t* __restrict__ ck_all, DenseRec* __restrict__ rec_all,
+                                                            DenseRec* __restrict__ rec_all, uint64_t* __restrict__ out_all,
                                                             uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
                                                             const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     constexpr uint32_t G = 64u * W;
     __shared__ uint32_t s_win[W][kWave * kSegRow];
-    __shared__ uint64_t s_in[G], s_out[G], s_exit[W];
-    __shared__ uint32_t s_cnt[G], s_bnd[G + 1], s_ckr[G];
+    __shared__ uint64_t s_exit[W];
+    __shared__ uint32_t s_cnt[G], s_bnd[G + 1], s_ck[G * kDenseCk];
     __shared__ uint32_t s_agg[W], s_aggcnt[W][8];
     __shared__ uint32_t s_bad;
     const uint32_t slot = blockIdx.x;
@@ -101,16 +181,13 @@ __global__ __launch_bounds__(64 * W, 4) void k_dense_frames(const uint8_t* __res
     uint32_t* const win = s_win[k];
     // regions of at least ~160 blocks: a link that meets a region's own walk only after the region's end has to cross it, and a
     // chain that has to cross regions all the time is a serial walk (small frames use fewer lanes)
-#ifdef TRPX_DENSE_DEBUG
-    const uint32_t g_eff = G;
-#else
-    const uint32_t g_eff = g.n_blocks / 160u < G ? (g.n_blocks / 160u ? g.n_blocks / 160u : 1u) : G;
-#endif
+    const uint32_t g_eff = g.n_blocks / kDenseSegBlocks < G ? (g.n_blocks / kDenseSegBlocks ? g.n_blocks / kDenseSegBlocks : 1u) : G;
     SegCtx c;
     if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, g_eff, status)) {
         if (threadIdx.x == 0) atomicMax(&status[0], 5u);
         return;
     }
+    c.L = (c.L + kSegAdv - 1u) / kSegAdv * kSegAdv;            // (a multiple of the window advance -- and of 128 bits, like seg_len_bits': every region's window grid is the frame's)
     uint8_t* const wf = widths + frame * g.n_blocks;
     uint64_t* const tf = tile_off + frame * g.n_tiles;
     seg_zero_widths(wf, g.n_blocks, k, W);
@@ -125,6 +202,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_dense_frames(const uint8_t* __res
     const uint32_t every = (n_win + kDenseCk - 2u) / (kDenseCk - 1u);
     const uint64_t seg0 = frame * G;
     DenseRec* const rec = rec_all + seg0 * kDenseSlots;
+    uint64_t* const g_out = out_all + seg0;
 
 #ifdef TRPX_DENSE_STAMPS
     const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime();
@@ -161,65 +239,55 @@ __global__ __launch_bounds__(64 * W, 4) void k_dense_frames(const uint8_t* __res
     uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
     bool bad = false;
     {
-        SegCk cks{ck_all + (seg0 + j) * kDenseCk, kDenseCk, every, 1u, 0u, false};
-        seg_walk<false>(c, win, 64u * k, walks, endB, false, pos, w, n, nullptr, nullptr, bad, nullptr, &cks);
-        s_ckr[j] = cks.t_first | (cks.t_last << 16);
+#pragma unroll
+        for (uint32_t i = 0; i < kDenseCk; ++i) s_ck[j * kDenseCk + i] = 0u;                                  // (no checkpoint)
+        DenseSpec sp{s_ck + j * kDenseCk, every, j * c.L};
+        seg_walk<false, DenseSpec>(c, win, 64u * k, walks, endB, false, pos, w, n, nullptr, nullptr, bad, nullptr, &sp);
     }
     const uint64_t out = seg_pack(pos, w);
-    s_in[j] = in; s_out[j] = out; s_cnt[j] = walks ? n : 0u; s_bnd[j] = B;
+    // the guess of the lane behind (a wavefront's lane 0 never takes a run guess)
+    uint64_t in_next = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)in, 1, 64) | ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(in >> 32), 1, 64) << 32);
+    if (lane == 63u) in_next = seg_pack((j + 1u) * c.L, 0u);
+    g_out[j] = out; s_cnt[j] = walks ? n : 0u; s_bnd[j] = B;
     __syncthreads();
 
 #ifdef TRPX_DENSE_STAMPS
     st_t1 = __builtin_amdgcn_s_memrealtime();
-#ifdef TRPX_SEG_STAMPS
-    if (threadIdx.x == 0 && slot % 125u == 0u) printf("dense spec: slot %u guess %u fill %u step %u\n", slot, (uint32_t)c.clk_guess, (uint32_t)c.clk_wait[0], (uint32_t)c.clk_step[0]);
-#endif
+
 #endif
     // ---- link: on from the OUT state into the regions behind, until the chain meets the walk of the lane that owns the region ----
+    // (the lane's windows simply go on: with L a multiple of the window advance the grids of all regions coincide, window t of this
+    // lane is window t - (s - j) L / 768 of region s)
     {
-        bool have = j + 1u < jl && out != s_in[j + 1u < G ? j + 1u : j];
-        uint32_t s = j + 1u, d = 1u, depth = 1u, n_entry = 0u;
+        DenseLink hk;
+        hk.s_ck = s_ck; hk.rec = rec; hk.g_out = g_out; hk.s_cnt = s_cnt; hk.s_bnd = s_bnd;
+        hk.j = j; hk.jl = jl; hk.n_w = c.L / kSegAdv; hk.every = every; hk.limit = c.limit;
+        hk.have = j + 1u < jl && out != in_next;
+        hk.s = j + 1u; hk.d = 1u; hk.depth = 1u; hk.n_entry = 0u;
+        hk.so = hk.have ? g_out[j + 1u] : 0ull;
         n = 0u;
-        while (__ballot(have)) {
+        uint32_t end2 = hk.have ? s_bnd[j + 2u] : 0u;
+        bool done2 = !hk.have;
+        if (hk.have) hk.region_end(pos, w, n, done2, end2);               // (a chain that is behind its first region already)
+        const uint32_t t_mine = hk.have && !done2 ? (pos - j * c.L) / kSegAdv : 0xFFFFFFFFu;
+        const uint32_t t_start = ~wave_max(~t_mine);
+        if (t_start != 0xFFFFFFFFu)
+            seg_walk<false, DenseLink>(c, win, 64u * k, hk.have && !done2, end2, false, pos, w, n, nullptr, nullptr, bad, nullptr, &hk, t_start);
 #ifdef TRPX_DENSE_STAMPS
-            ++st_depths;
+        st_depths = hk.depth;
 #endif
-            const uint32_t ss = have ? s : 0u;
-            const SegOrigin org{ss * c.L, 0u};
-            const uint32_t end2 = have ? s_bnd[ss + 1u] : 0u;
-            const uint32_t ckr = s_ckr[ss];
-            SegLink lk{ck_all + (seg0 + ss) * kDenseCk, every, have ? ckr & 0xFFFFu : 1u, have ? ckr >> 16 : 0u, false, 0u};
-            seg_walk<false>(c, win, 0u, have, end2, false, pos, w, n, nullptr, nullptr, bad, &org, nullptr, &lk);
-            if (have) {
-                DenseRec r;
-                const uint32_t at = s * kDenseSlots + d - 1u;
-                const uint64_t so = s_out[s], here = seg_pack(pos, w);
-                if (pos > c.limit) { r = DenseRec{0ull, 0u, kRecFail}; have = false; }                       // (a chain that left the frame: not the frame's)
-                else if (lk.merged) { r = DenseRec{so, (n - n_entry) + (s_cnt[s] - lk.ck_cnt), kRecMerged}; have = false; }
-                else if (here == so) { r = DenseRec{so, n - n_entry, kRecMerged}; have = false; }            // merged by the region's end
-                else {
-                    r = DenseRec{here, n - n_entry, kRecThrough};
-                    if (s + 1u >= jl) have = false;                                                           // the last counted region: the tail starts here
-                    else if (++depth > kDenseMaxDepth) { r.flag = kRecFail; have = false; }
-                    else { ++s; d = d < kStDeep ? d + 1u : kStDeep; n_entry = n; }
-                }
-                rec[at] = r;
-            }
-        }
     }
     __syncthreads();
 
 #ifdef TRPX_DENSE_STAMPS
     st_t2 = __builtin_amdgcn_s_memrealtime();
-#ifdef TRPX_SEG_STAMPS
-    if (threadIdx.x == 0 && slot % 125u == 0u) printf("dense link: slot %u fill %u step %u (incl. spec)\n", slot, (uint32_t)c.clk_wait[0], (uint32_t)c.clk_step[0]);
-#endif
+
 #endif
     // ---- resolve: the true walk of every region, its first block, its start state ---------------------------------------------------
     uint32_t tbl = kDenseIdent, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
     DenseRec r1{}, r2{}, r3{}, r4{}, r5{}, r6{};
     if (j < jl) {
-        const uint32_t mex = j + 1u < G && s_in[j + 1u] == out ? 0u : 1u;      // behind a merged walk: lane j + 1's own walk if its guess was my OUT state, else my link
+        const uint32_t mex = in_next == out ? 0u : 1u;      // behind a merged walk: lane j + 1's own walk if its guess was my OUT state, else my link
         tbl = mex;                                                              // state 0: the lane's own walk -- true in segment 0 and behind a closed link
         c0 = s_cnt[j];
         if (j > 0u) {
@@ -294,22 +362,8 @@ __global__ __launch_bounds__(64 * W, 4) void k_dense_frames(const uint8_t* __res
         if (part && !last && (seg_pack(pos, w) != exit_state || n != my_base + my_cnt)) bad = true;
         if (part && last && !(n == g.n_blocks && pos <= c.limit && 1u + pos / 8u == c.limit / 8u)) bad = true;   // S_f = 1 + bits/8 (Terse.hpp:547)
         if (serial) {
-#ifdef TRPX_DENSE_DEBUG
-            __builtin_amdgcn_s_waitcnt(0);
-            if (lane == 0u && frame == 31u) {
-                printf("dense: frame %u serial: bad %d n %u of %u pos %u limit %u wf %p\n", (uint32_t)frame, (int)bad, n, g.n_blocks, pos, c.limit, (void*)wf);
-                for (uint32_t b = 180; b < 250; b += 10) {
-                    uint32_t v[10];
-                    for (uint32_t q = 0; q < 10; ++q) v[q] = __hip_atomic_load(wf + b + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    printf("   w[%u..] = %u %u %u %u %u %u %u %u %u %u\n", b, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
-                }
-            }
-#endif
             if (__ballot(bad) && lane == 0u) atomicMax(&status[0], 5u);         // TRPX_ERR_CORRUPT: the serial walk's verdict
         } else {
-#ifdef TRPX_DENSE_DEBUG
-            if (bad) printf("dense: frame %u attempt 0: lane %u bad (part %d last %d) n %u pos %u w %u want %llx base %u jl %u\n", (uint32_t)frame, j, (int)part, (int)last, n, pos, w, (unsigned long long)exit_state, my_base, jl);
-#endif
             if (__ballot(bad) && lane == 0u) s_bad = 1u;
             __syncthreads();
         }
@@ -322,16 +376,15 @@ __global__ __launch_bounds__(64 * W, 4) void k_dense_frames(const uint8_t* __res
 hipError_t launch_dense_listed(const DecodeArgs& a, uint32_t max_w, void* dense_ws, const uint32_t* list, hipStream_t st) {
     const uint32_t W = dense_waves(a.geom);
     const size_t segs = (size_t)a.n_frames * 64u * W;
-    uint64_t* ck = static_cast<uint64_t*>(dense_ws);
-    DenseRec* rec = reinterpret_cast<DenseRec*>(ck + segs * kDenseCk);
+    DenseRec* rec = static_cast<DenseRec*>(dense_ws);
+    uint64_t* outs = reinterpret_cast<uint64_t*>(rec + segs * kDenseSlots);
 #define TRPX_DENSE_LAUNCH(WW)                                                                                                             \
     hipLaunchKernelGGL((k_dense_frames<WW>), dim3(a.n_frames), dim3(64 * WW), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, \
-                       a.geom, max_w, ck, rec, a.widths, a.tile_off, list, a.status)
+                       a.geom, max_w, rec, outs, a.widths, a.tile_off, list, a.status)
     switch (W) {
     case 1: TRPX_DENSE_LAUNCH(1); break;
     case 2: TRPX_DENSE_LAUNCH(2); break;
-    case 4: TRPX_DENSE_LAUNCH(4); break;
-    default: TRPX_DENSE_LAUNCH(8); break;
+    default: TRPX_DENSE_LAUNCH(4); break;
     }
 #undef TRPX_DENSE_LAUNCH
     return hipGetLastError();

@@ -589,7 +589,7 @@ size_t seg_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     // behind the segment states: the scratch of the listed frames' dense walk (decode_dense.hip; frames of one wavefront's worth here)
     return seg_state_bytes(g, n_frames) + (seg_waves_per_frame(g, n_frames) == 1 ? dense_workspace_bytes(g, n_frames) : 0);
 }
-static bool g_dense_route = true;
+static bool g_dense_route = false;   // (off: measured slower than the rounds on Poisson(3) counts, see LABNOTES round 6; trpx_set_decode_path(6) / TRPX_DECODE_PATH=dense)
 void set_dense_route(bool on) { g_dense_route = on; }
 
 hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st, const uint32_t* list = nullptr);   // decode_fast.hip

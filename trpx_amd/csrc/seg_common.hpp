@@ -70,36 +70,19 @@ struct SegOrigin {
     uint32_t n_end;      // a by_count lane stops at n == n_end
 };
 
-// (decode_dense.hip) A counting lane leaves its state at every window boundary it crosses: ck[t] = the state at the first block
-// start at or behind X + 768 t and the blocks counted up to it -- a chain that arrives there in the same state has merged with
-// this one.  Boundaries [t_first, t_last] were recorded (none: t_first > t_last); over: one did not fit.
-struct SegCk {
-    uint64_t* ck;
-    uint32_t cap, every;      // every: only boundaries t = every * i are recorded, as entry i (long segments)
-    uint32_t t_first, t_last; // out: entries recorded
-    bool over;
-};
-__device__ __forceinline__ uint64_t seg_ck_pack(uint32_t pos, uint32_t w, uint32_t cnt) {
-    return (uint64_t)pos | ((uint64_t)(w & 63u) << 32) | ((uint64_t)cnt << 38);
-}
-
-// (decode_dense.hip) A LINK walk -- a chain that enters another lane's region -- compares its state with that lane's checkpoints
-// at every boundary it crosses (the window grids coincide: org->X = the region's segment start) and stops where the two chains
-// have merged: the rest of that lane's walk is this chain's.  The checkpoint is requested when the window opens and read when it
-// closes (a global load per window, in the shadow of the window's steps).
-struct SegLink {
-    const uint64_t* ck;       // the region's checkpoints
-    uint32_t every;           // (see SegCk)
-    uint32_t first, last;     // entries that lane recorded
-    bool merged;              // out
-    uint32_t ck_cnt;          // out: that lane's block count at the merge
+// A caller's hook into a counting walk (decode_dense.hip: the link walks that go on across regions): open() when a window opens,
+// close() when no lane is active in it any more -- it may change a lane's `end` / `done` and returns true for a lane that has
+// more steps to take in this window.
+struct SegNoHook {
+    __device__ __forceinline__ void open(uint32_t, bool) {}
+    __device__ __forceinline__ bool close(uint32_t, bool, uint32_t, uint32_t&, uint32_t&, uint32_t&, bool&, uint32_t&) { return false; }
 };
 
-template <bool WRITE>
+template <bool WRITE, class Hook = SegNoHook>
 __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__ win, uint32_t seg0, bool part, uint32_t end,
                                          bool by_count, uint32_t& pos, uint32_t& w, uint32_t& n,
                                          uint8_t* __restrict__ wf, uint64_t* __restrict__ tf, bool& bad, const SegOrigin* org = nullptr,
-                                         SegCk* cks = nullptr, SegLink* lk = nullptr) {
+                                         Hook* hook = nullptr, uint32_t t_start = 0u) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t X = org ? org->X : (seg0 + lane) * c.L;
     const uint32_t wsh = org ? (uint32_t)((c.fa + X) & 127u) : c.wsh;      // bit offset of the window's first wanted bit in its 16-byte aligned load
@@ -128,8 +111,8 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         }
     };
     uint64_t live = __ballot(!done);
-    if (live) fetch(0, live);
-    for (uint32_t t = 0; live; ++t) {
+    if (live) fetch(t_start, live);
+    for (uint32_t t = t_start; live; ++t) {
 #ifdef TRPX_SEG_STAMPS
         const uint64_t clk0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -141,25 +124,20 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t w0 = X + t * kSegAdv, wend = w0 + kSegAdv;
+        bool act = !done && pos < wend;
+        [[maybe_unused]] const bool act0 = act;
+        // (the hook's loads in FRONT of the next window's: loads return in order, and what is needed when this window closes must
+        // not wait behind eight loads that are needed a window later)
+        if constexpr (!WRITE) { if (hook) hook->open(t, act0); }
         fetch(t + 1, live);                                   // prefetch: consumed at the top of the next iteration
 #ifdef TRPX_SEG_STAMPS
         const uint64_t clk1 = __builtin_amdgcn_s_memrealtime();
         c.clk_wait[WRITE] += clk1 - clk0;
 #endif
-        const uint32_t w0 = X + t * kSegAdv, wend = w0 + kSegAdv;
-        bool act = !done && pos < wend;
-        [[maybe_unused]] const bool act0 = act;
-        [[maybe_unused]] uint64_t lk_ck = 0ull;
-        [[maybe_unused]] bool lk_have = false;
-        if constexpr (!WRITE) {
-            if (lk) {
-                const uint32_t i = (t + 1u) / lk->every;
-                lk_have = act0 && i * lk->every == t + 1u && i >= lk->first && i <= lk->last;
-                if (lk_have) lk_ck = lk->ck[i];
-            }
-        }
         // Every lane executes every step (no exec-mask juggling, one branch per step); a lane that is not active
         // computes on a stale position and keeps its state.
+        for (bool again = true; again;) {
         while (__ballot(act)) {
 #ifdef TRPX_SEG_STATS
             if (lane == 0u) atomicAdd(c.stat + 3, 1u);
@@ -376,21 +354,14 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             done = done || pos > c.limit;
             act = !done && pos < wend;
         }
+        again = false;
         if constexpr (!WRITE) {
-            if (lk && lk_have && !done && pos >= wend && (uint32_t)lk_ck == pos && (uint32_t)((lk_ck >> 32) & 63u) == w) {
-                lk->merged = true; lk->ck_cnt = (uint32_t)(lk_ck >> 38);
-                done = true;
+            if (hook) {
+                const bool more = hook->close(t, act0, wend, pos, w, n, done, end);
+                act = more && !done && pos < wend;
+                again = __ballot(act) != 0ull;
             }
-            if (cks && act0 && pos >= wend) {                 // crossed the boundary of window t + 1
-                const uint32_t i = (t + 1u) / cks->every;
-                if (i * cks->every == t + 1u) {
-                    if (i < cks->cap) {
-                        cks->ck[i] = seg_ck_pack(pos, w, n);
-                        if (cks->t_first > cks->t_last) cks->t_first = i;
-                        cks->t_last = i;
-                    } else cks->over = true;
-                }
-            }
+        }
         }
         __builtin_amdgcn_wave_barrier();                      // every lane is through with this window before it is overwritten
 #ifdef TRPX_SEG_STAMPS
