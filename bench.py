@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spawn-dry-run", action="store_true",
                     help="print the per-rank command lines / environments `--gpus N` would start, and exit (no GPU call)")
+    ap.add_argument("--allow-gather-fallback", action="store_true",
+                    help="N > 1: if the C-ABI RCCL size gather cannot be set up, exchange the sizes through torch.distributed instead of failing")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the informative legs (configs[3], noisy_u16, index decode): profiler passes see the headline kernels only")
     args = ap.parse_args()
@@ -238,6 +240,10 @@ def main():
         else:
             if gather is not None:
                 gather.close()
+            if not args.allow_gather_fallback:
+                # the metric names RCCL's size gather: a run that silently measured another exchange would not be that metric
+                sys.exit(f"bench.py rank {rank}: the C-ABI RCCL size gather could not be set up on every rank (see stderr); "
+                         "--allow-gather-fallback exchanges the sizes through torch.distributed instead")
             tg = sharded.SizeGather(frames, dev)
             gather = lambda o, st: tg(o, st[1:2])                                     # noqa: E731
             gather.close = lambda: None
@@ -276,10 +282,20 @@ def main():
         enc = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_fps_min = rank_fps_max = rccl_ranks = None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine = args.steps * frames / elapsed                 # this rank's own frames/s over its own clock
+        t = torch.tensor([elapsed, -mine, mine], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, rank_fps_min, rank_fps_max = float(t[0].item()), -float(t[1].item()), float(t[2].item())
+        # how many ranks the size gather's communicator spans, as RCCL itself reports it (ncclCommCount), agreed over all ranks
+        info = list(gather.rccl_info()) if one_call else [0, rank]
+        ri = torch.tensor([info[0], -info[0], int(info[1] == rank)], dtype=torch.int32, device=dev)
+        dist.all_reduce(ri, op=dist.ReduceOp.MIN)
+        rccl_ranks = int(ri[0].item())
+        if one_call:
+            assert rccl_ranks == world and -int(ri[1].item()) == world and int(ri[2].item()) == 1, \
+                f"RCCL communicator spans {info[0]} ranks (rank {info[1]}) but the job has {world} (rank {rank})"
 
     # ---- correctness of what was just timed (every rank) -----------------------------------
     assert int(st_e[0].item()) == 0 and int(st_d[0].item()) == 0, "device status reports an error"
@@ -567,7 +583,12 @@ def main():
                                    f"(configs[1]) + Prolix decode (configs[2])",
                        "frames_per_gpu": frames, "n_values": N_VALUES, "block": 12,
                        "parallelism": f"frames sharded {world}-way, RCCL all-gather of per-frame sizes",
-                       "size_gather": gather_kind},
+                       "size_gather": gather_kind,
+                       # self-verification of a sharded run (N > 1): which exchange was timed, how many ranks RCCL's communicator
+                       # spans (ncclCommCount through trpx_comm_info, agreed over all ranks; 0: not the C-ABI path), and the
+                       # slowest / fastest rank's own frames/s
+                       "size_gather_path": (None if not use_dist else "c_abi_rccl" if one_call else "torch_distributed_fallback"),
+                       "rccl_ranks": rccl_ranks, "rank_frames_per_s_min": rank_fps_min, "rank_frames_per_s_max": rank_fps_max},
             "roundtrip_GBps_pixels": world * frames * N_VALUES * 2 * 2 * args.steps / elapsed / 1e9,
             "roofline": roofline,
         }

@@ -389,6 +389,9 @@ int trpx_decode_sharded(int stream_signed, int out_dtype, const uint8_t* local_t
 int trpx_comm_unique_id(void* id128);
 int trpx_comm_init(void** comm, int world, int rank, const void* id128);
 int trpx_comm_destroy(void* comm);
+/* What RCCL itself says about a communicator (ncclCommCount / ncclCommUserRank): a caller that reports a sharded run can state
+ * how many ranks the size gather really spanned.  Either pointer may be NULL. */
+int trpx_comm_info(void* comm, int* world, int* rank);
 const char* trpx_shard_last_error(void);
 
 #ifdef __cplusplus

@@ -1451,6 +1451,34 @@ print("OK", total)
         assert r.returncode == 0 and "OK" in r.stdout, (name, r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_listed_large_frames_fallback_on_a_small_device(gpu, oracle, tmp_path):
+    """k_seg_fallback (decode_seg.hip) synchronises its persistent grid with device-wide barriers, which needs every workgroup
+    resident at once: the grid is sized by what the device holds (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, halved,
+    at most 1024).  Test build `segfbgrid`: a device that holds 24.  Header-dense frames of 1030 x 1065 and 2048 x 520 pixels
+    are listed by the large-frame routes and must come out exact through the 24-workgroup grid (status 0, no timeout)."""
+    variant = os.path.join(ROOT, "tools", "variants", "libtrpx_segfbgrid.so")
+    if not os.path.exists(variant):
+        pytest.skip("test variant not built (make -C trpx_amd/csrc segfbgrid)")
+    script = tmp_path / "t.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from trpx_amd import codec, _lib, workloads
+for route in (0, 2, 4):
+    _lib.lib().trpx_set_decode_path(route)
+    for n, frames in ((1030 * 1065, 5), (2048 * 520, 3)):
+        px = workloads.poisson_u16(3.0, 0, frames, n, device="cuda")
+        enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and torch.equal(back.view(torch.int16), px.view(torch.int16)), (route, n, frames, st.tolist())
+print("OK")
+""")
+    r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_many_large_frames_stay_whole(gpu, oracle):
     """Stacks of 768 frames and more keep frames of more than 32 K blocks on the per-frame route (one workgroup per frame,
     header-dense frames handed to the one-wavefront position-parallel walk) instead of cutting them into parts

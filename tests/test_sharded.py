@@ -35,6 +35,13 @@ def _worker(rank, world, port, total_frames, q):
     counts = [sharded.frame_range(total_frames, r, world)[1] - sharded.frame_range(total_frames, r, world)[0] for r in range(world)]
     goffs2, base2, gpb2 = sharded.gather_global_offsets(local_offsets, torch.tensor([pb]), counts=counts)
     assert torch.equal(goffs, goffs2) and int(base) == int(base2) and int(gpb) == int(gpb2)
+    # trpx_decode_sharded's first step (shard.hip: k_rebase_offsets), host-side: this rank's offsets back out of the GLOBAL table --
+    # ragged shards included -- are the offsets its own encode wrote, and its frames decode from them
+    mine = sharded.rebase_offsets(goffs, lo, hi - lo)
+    assert torch.equal(mine, local_offsets) and int(goffs[lo]) == int(base)
+    for f in (0, hi - lo - 1):
+        got = O.decode(data[int(mine[f]): int(mine[f + 1])], n, np.uint16)
+        assert (got == px[f]).all()
     if total_frames % world == 0:                           # equal shards: the preallocated gather bench.py overlaps with decode
         sg = sharded.SizeGather(hi - lo, "cpu")
         for _ in range(2):                                   # buffers are reused call after call

@@ -64,6 +64,7 @@ SYMBOLS = {
     "trpx_comm_unique_id": (_I, [_P]),
     "trpx_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
     "trpx_comm_destroy": (_I, [_P]),
+    "trpx_comm_info": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "trpx_shard_last_error": (C.c_char_p, []),
     "trpx_stack_open": (_I, [C.POINTER(_P), _I, _P, _SZ, _P, _P, _SZ, _SZ, _U, _U, _I]),
     "trpx_group_count": (_SZ, [_SZ, _U]),

@@ -322,7 +322,7 @@ int trpx_decode(int stream_signed, int out_dtype, const uint8_t* terse, size_t t
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
     // larger frames, or frames of more than 32 K blocks: cut into parts of the size of a 512 x 512 frame first (decode_part.hip);
     // a part's positions are relative to its own first bit, so the 2^26 limit applies to the part
-    a.chain = route != 4 && bits32;                                            // (frame-relative 32-bit positions)
+    a.chain = route != 4 && route != 2 && bits32;                              // (frame-relative 32-bit positions; a forced tiled route walks large frames position-parallel, as build_index_impl does)
     a.parts_per_frame = a.chain ? trpx::chain_parts_per_frame(g, n_frames, trpx_dtype_size(out_dtype)) : trpx::parts_per_frame(g, n_frames);
     const bool parts_ok = a.parts_per_frame > 1u && n_frames * (uint64_t)a.parts_per_frame < 0x7FFFFFFFull && a.defer;
     if (parts_ok) {

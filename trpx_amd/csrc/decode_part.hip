@@ -1012,7 +1012,7 @@ struct ChainFix {                              // what k_chain_repair leaves per
 struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, total; };
 static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     ChainWs w;
-    w.states = 0;                                                             // [states, fixes): start states and walk records with their ready / published bits, cleared in front of every call (launch_chain_zero)
+    w.states = 0;                                                             // [states, cks): start states, walk records (with their ready / published bits) and link records, cleared in front of every call (launch_chain_zero)
     w.walks = align_up(w.states + n_frames * P * sizeof(PartState), 256);
     w.fixes = align_up(w.walks + n_frames * P * sizeof(PartWalk), 256);
     w.cks = align_up(w.fixes + n_frames * P * sizeof(ChainFix), 256);
@@ -1085,6 +1085,10 @@ __device__ __forceinline__ PartWalk chain_walk_wait(const PartWalk* src) {
             __builtin_amdgcn_s_sleep(64);
             if (__builtin_amdgcn_s_memrealtime() - t0 > kChainWaitTicks) { v[1] = 1ull << 32; break; }   // 0.25 s: a bad walk
         }
+        // (the record's other words -- and whatever the caller reads of the part's checkpoints -- only after the published bit has
+        // been SEEN: the flag's value has arrived here, the statement keeps the compiler from moving the relaxed loads below
+        // in front of it; the hardware returns loads in order)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v[2] = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v[3] = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1120,6 +1124,7 @@ __device__ __forceinline__ bool chain_walk_poll(const PartWalk* src, PartWalk& r
     if (lane_id() == 0) {
         v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (((v[1] >> 32) & kWalkPublished) != 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (as in chain_walk_wait)
             v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[2] = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[3] = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1645,7 +1650,9 @@ __global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict
 }
 
 // The words the index route needs cleared in front of every call: the status block (if asked), the deferred-frame count and the
-// stack statistics in front of it, and the route's start states and walk records (ChainWs: [states, fixes)).  One launch.
+// stack statistics in front of it, and the route's start states, walk records and link records (ChainWs: [states, cks) -- the
+// link records too: a wavefront that skips a link writes none, and a record left by an earlier call must not be read as this
+// call's).  One launch.
 __global__ __launch_bounds__(kThreads) void k_chain_zero(uint64_t* __restrict__ p, uint64_t n, uint64_t* __restrict__ q, uint64_t m,
                                                          uint64_t* __restrict__ r, uint64_t k) {
     const uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kThreads;
@@ -1657,7 +1664,7 @@ hipError_t launch_chain_zero(const DecodeArgs& a, bool clear_status, hipStream_t
     const uint32_t P = a.parts_per_frame;
     if (P < 4u || !a.part_ws || !a.defer) return hipErrorInvalidValue;
     const ChainWs l = chain_ws_layout(a.geom, a.n_frames, P);
-    const uint64_t k = l.fixes / 8;
+    const uint64_t k = l.cks / 8;
     hipLaunchKernelGGL(k_chain_zero, dim3((uint32_t)((k + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, st,
                        reinterpret_cast<uint64_t*>(a.defer) - kDeferSlots * kDeferSlotWords, (uint64_t)(kDeferSlots * kDeferSlotWords + 1),
                        reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0), reinterpret_cast<uint64_t*>(a.part_ws), k);

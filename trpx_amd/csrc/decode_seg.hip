@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kWave) void k_seg_write(const uint8_t* __restrict__
 // of each phase -- rounds x 3, resolve, write, the serial walk of frames that did not converge -- with a device-wide barrier
 // between them (a counter every workgroup adds to and waits for, the waits bounded like the encoder's look-back; all kSegFbGrid
 // workgroups are resident at once: 64 threads, 16.6 KB of LDS each).  Results are what the six launches produce.
-constexpr uint32_t kSegFbGrid = 1024;
+constexpr uint32_t kSegFbGrid = 1024;            // at most; the launch asks the device how many of these workgroups it holds at once (seg_fallback_grid)
 __device__ __forceinline__ bool seg_grid_barrier(uint64_t* __restrict__ ctr, uint32_t& epoch) {
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -594,6 +594,27 @@ void set_dense_route(bool on) { g_dense_route = on; }
 
 hipError_t launch_walk_lds_only(const DecodeArgs& a, uint32_t max_w, const uint32_t* only, hipStream_t st, const uint32_t* list = nullptr);   // decode_fast.hip
 
+// k_seg_fallback's device-wide barriers need every workgroup of the grid resident at once: as many as the device holds (a
+// partitioned or CU-masked device, another architecture: fewer than kSegFbGrid), at most kSegFbGrid; half of what fits, so that
+// kernels of other streams -- the size gather of the sharded entry points -- leave room.  Cached per device.
+static uint32_t seg_fallback_grid() {
+    static thread_local int cached_dev = -1;
+    static thread_local uint32_t cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 64u;
+    if (dev == cached_dev && cached) return cached;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_fallback, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
+    uint64_t fit = (uint64_t)per_cu * (uint64_t)cus / 2u;
+#ifdef TRPX_SEG_FB_GRID
+    fit = TRPX_SEG_FB_GRID;                                                    // (test build: a device that holds this many)
+#endif
+    cached = (uint32_t)(fit < 1u ? 1u : (fit > kSegFbGrid ? kSegFbGrid : fit));
+    cached_dev = dev;
+    return cached;
+}
+
 // Fills a.widths / a.tile_off (the decode index) from the stream.
 // Several wavefronts per frame: every frame of the stack (list == nullptr) or the frames of a list.
 static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t K, const uint32_t* list, hipStream_t st) {
@@ -602,7 +623,7 @@ static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t
         // the barrier counter: the last word of the statistics slots in front of the list (codec_common.hpp), cleared with them by
         // the call's first launch and used by nothing else
         uint64_t* barrier = reinterpret_cast<uint64_t*>(a.defer) - 1;
-        hipLaunchKernelGGL(k_seg_fallback, dim3(kSegFbGrid), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
+        hipLaunchKernelGGL(k_seg_fallback, dim3(seg_fallback_grid()), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
                            max_w, K, ws, a.widths, a.tile_off, list, barrier, a.status);
         return hipGetLastError();
     }

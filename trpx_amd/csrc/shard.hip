@@ -287,6 +287,24 @@ int trpx_comm_init(void** comm, int world, int rank, const void* id128) {
     return TRPX_OK;
 }
 
+int trpx_comm_info(void* comm, int* world, int* rank) {
+    const Rccl& R = rccl();
+    if (!R.ok) return shard_fail(TRPX_ERR_UNSUPPORTED, "trpx_comm_info", R.why);
+    if (!comm) return shard_fail(TRPX_ERR_INVALID_ARG, "trpx_comm_info", "null communicator");
+    int v = 0;
+    if (world) {
+        const ncclResult_t rc = R.CommCount(static_cast<ncclComm_t>(comm), &v);
+        if (rc != ncclSuccess) return shard_fail(TRPX_ERR_HIP, "ncclCommCount", R.GetErrorString(rc));
+        *world = v;
+    }
+    if (rank) {
+        const ncclResult_t rc = R.CommUserRank(static_cast<ncclComm_t>(comm), &v);
+        if (rc != ncclSuccess) return shard_fail(TRPX_ERR_HIP, "ncclCommUserRank", R.GetErrorString(rc));
+        *rank = v;
+    }
+    return TRPX_OK;
+}
+
 int trpx_comm_destroy(void* comm) {
     const Rccl& R = rccl();
     if (!R.ok || !comm) return TRPX_OK;

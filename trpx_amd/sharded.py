@@ -55,6 +55,15 @@ def gather_global_offsets(local_offsets: torch.Tensor, local_prolix_bits: torch.
     return global_offsets, my_base, pb
 
 
+def rebase_offsets(global_offsets: torch.Tensor, first_frame: int, n_local: int) -> torch.Tensor:
+    """A rank's frame offsets relative to its own first byte, from the global table: what trpx_decode_sharded computes on the
+    device in front of its decode (shard.hip: k_rebase_offsets -- local[i] = global[first + i] - global[first], i = 0 .. n_local).
+    Host-side statement of the same arithmetic, for ragged shards too (tests/test_sharded.py drives it over gloo)."""
+    g = global_offsets[first_frame: first_frame + n_local + 1]
+    assert g.numel() == n_local + 1, "the global table does not hold this rank's frames"
+    return g - g[0]
+
+
 class SizeGather:
     """The same exchange for a fixed, equal shard size, with every buffer allocated once: five small launches and one
     collective per call, meant to run on its own stream next to the decode (which does not need the global offsets)."""
@@ -131,6 +140,12 @@ class RcclSizeGather:
                                                       self.rank_base.data_ptr(), self.ws.data_ptr(), self.ws.numel(), st))
         return self.global_offsets, self.rank_base[self.rank], self.prolix[0]
 
+    def rccl_info(self):
+        """(ranks, rank) of the communicator as RCCL reports them (ncclCommCount / ncclCommUserRank through trpx_comm_info)."""
+        w, r = C.c_int(-1), C.c_int(-1)
+        self._check(self._L.trpx_comm_info(self.comm, C.byref(w), C.byref(r)))
+        return int(w.value), int(r.value)
+
     def close(self) -> None:
         if self.comm:
             self._L.trpx_comm_destroy(self.comm)
@@ -163,8 +178,13 @@ class ShardedCodec(RcclSizeGather):
 
     def encode(self, pixels: torch.Tensor, gather_stream: "torch.cuda.Stream | None" = None):
         """pixels: [frames_per_rank, n_values] on this rank's GPU.  Stream-ordered on the current stream (the gather on
-        `gather_stream` if given).  Returns (global_offsets, my_base, prolix_bits) as views of internal buffers."""
+        `gather_stream` if given).  Returns (global_offsets, my_base, prolix_bits) as views of internal buffers.
+
+        A gather on a side stream writes global_offsets / prolix / rank_base there while it still reads local_offsets and
+        status: the object remembers that stream, and the next encode() or decode() -- or join() -- makes the current stream
+        wait for it first (include/trpx_hip.h: the caller joins the two streams where it reads the table)."""
         assert pixels.is_cuda and pixels.shape[0] == self.f and pixels[0].numel() == self.n_values and pixels.dtype == self.tdt
+        self.join(pixels.device)                               # (a gather of the call before may still be reading what this call overwrites)
         st = torch.cuda.current_stream(pixels.device).cuda_stream
         with torch.cuda.device(pixels.device):
             self._check(self._L.trpx_encode_sharded(self.comm, self.code, pixels.data_ptr(), self.n_values, self.f, self.f, self.block,
@@ -172,13 +192,22 @@ class ShardedCodec(RcclSizeGather):
                                                     self.global_offsets.data_ptr(), self.prolix.data_ptr(), self.rank_base.data_ptr(),
                                                     self.ws_e.data_ptr(), self.ws_e.numel(), st,
                                                     gather_stream.cuda_stream if gather_stream is not None else None))
+        self._gather_stream = gather_stream
         return self.global_offsets, self.rank_base[self.rank], self.prolix[0]
+
+    def join(self, device=None):
+        """Makes the current stream wait for the last encode()'s gather if that ran on a side stream."""
+        gs = getattr(self, "_gather_stream", None)
+        if gs is not None:
+            torch.cuda.current_stream(device if device is not None else gs.device).wait_stream(gs)
+            self._gather_stream = None
 
     def decode(self, out: torch.Tensor, stream_signed: bool | None = None):
         """Expands this rank's frames (the bytes `encode` left in self.out) from the global offset table into `out`."""
         assert out.is_cuda and out.numel() == self.f * self.n_values and out.dtype == self.tdt
         if stream_signed is None:
             stream_signed = bool(self._L.trpx_dtype_is_signed(self.code))
+        self.join(out.device)                                  # (the global table may come from a side stream)
         st = torch.cuda.current_stream(out.device).cuda_stream
         with torch.cuda.device(out.device):
             self._check(self._L.trpx_decode_sharded(int(stream_signed), self.code, self.out.data_ptr(), self.out.numel(),
