@@ -133,6 +133,11 @@ def test_synth_generator_matches_oracle(gpu, oracle):
         assert (dev == oracle.synth(dt, 5, 3, n)).all()
 
 
+def _synth_anchors():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "synth_anchors.json")))["anchors"]
+
+
 def test_synth_anchors_u16_512(gpu, golden):
     """configs[1]/[2] data: GPU stream of frames 0..2 hashes to what the REAL reference produced."""
     import torch
@@ -167,15 +172,21 @@ def test_synth_anchor_i32_4096(gpu, golden):
     from oracle import oracle as O
     a = [x for x in golden["anchors"] if x["dtype"] == "int32"][0]
     n = a["n"]
-    px = codec.synth(np.int32, 0, 2, n, device=gpu)
+    # ... and frames 1 .. 7 -- the eight frames bench.py times -- from tests/golden/synth_anchors.json (the real reference again:
+    # tests/golden/make_anchors.py)
+    more = [x for x in _synth_anchors() if x["dtype"] == "int32"]
+    assert [x["frame"] for x in more] == list(range(1, 8))
+    px = codec.synth(np.int32, 0, 8, n, device=gpu)
     enc = codec.encode(px)
     torch.cuda.synchronize()
     enc.check()
     offs = enc.frame_offsets.cpu().numpy()
-    s = enc.data[: offs[1]].cpu().numpy()
-    assert s.size == a["size"] and enc.prolix_bits() == a["prolix_bits"]
-    assert f"{O.fnv1a64(s):016x}" == a["stream_fnv"]
-    back, status = codec.decode(enc.stack(), enc.frame_offsets, n, 2, np.int32)
+    for x in [a] + more:
+        f = x["frame"]
+        s = enc.data[offs[f]: offs[f + 1]].cpu().numpy()
+        assert s.size == x["size"] and enc.prolix_bits() == x["prolix_bits"], f
+        assert f"{O.fnv1a64(s):016x}" == x["stream_fnv"] and s[:16].tobytes().hex() == x["first16"], f
+    back, status = codec.decode(enc.stack(), enc.frame_offsets, n, 8, np.int32)
     torch.cuda.synchronize()
     assert int(status[0].item()) == 0 and torch.equal(back, px)
 
@@ -204,6 +215,14 @@ def test_full_stack_2000_frames_properties(gpu):
         a, b = int(offs[f].item()), int(offs[f + 1].item())
         assert single.total_bytes() == b - a
         assert torch.equal(single.stack(), enc.data[a:b])
+    # frames 1000 and 1999 against what the REAL reference made of them (tests/golden/synth_anchors.json)
+    from oracle import oracle as O
+    for x in [x for x in _synth_anchors() if x["dtype"] == "uint16"]:
+        f = x["frame"]
+        a, b = int(offs[f].item()), int(offs[f + 1].item())
+        s = enc.data[a:b].cpu().numpy()
+        assert s.size == x["size"] and f"{O.fnv1a64(s):016x}" == x["stream_fnv"] and s[:16].tobytes().hex() == x["first16"], f
+        assert f"{O.fnv1a64(px[f].cpu().numpy()):016x}" == x["pixels_fnv"], f
 
 
 def test_capacity_error_and_sizes_only_query(gpu):
@@ -1154,6 +1173,27 @@ def test_build_index_of_many_small_frames(gpu, oracle, dtype):
         back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt, index=walked)
         torch.cuda.synchronize()
         assert int(st[0]) == 0 and (back.cpu().numpy().reshape(frames, n).view(dt) == px).all(), (dtype, kind, n, frames)
+
+
+@pytest.mark.parametrize("route", ["auto", "tiles", "frames", "parts", "dense", "basic"])
+def test_fuzz_slice_every_route(gpu, oracle, route):
+    """A bounded, seeded slice of tools/fuzz_paths.py inside the tier the driver runs: random pixel types, frame sizes (small,
+    512 x 512, detector sizes beyond 32 K blocks), frame counts and width patterns (runs, flips, pedestals, Poisson counts, type
+    extremes), encoded by the GPU (== the oracle's bytes), decoded along the forced route (== the pixels), the decode index
+    three ways.  6 - 10 s per route; the long runs stay with the tool (profiles/rNN_fuzz.txt)."""
+    import importlib.util
+    from trpx_amd import _lib
+    spec = importlib.util.spec_from_file_location("fuzz_paths", os.path.join(ROOT, "tools", "fuzz_paths.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    code = {"auto": 0, **_ROUTES}[route]
+    assert _lib.lib().trpx_set_decode_path(code) == 0
+    try:
+        n_run, n_large, n_fb = fz.run(60, seed=600 + code, basic=route == "basic", budget_s=6.0, quiet=True,
+                                      max_pixels=1 << (21 if route in ("basic", "frames") else 23))
+    finally:
+        _lib.lib().trpx_set_decode_path(0)
+    assert n_run >= 8, n_run
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)

@@ -8,6 +8,8 @@ keeps / writes its frames at the global byte offsets computed here.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
