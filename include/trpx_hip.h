@@ -145,7 +145,13 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
  *   trpx_encode_indexed   = trpx_encode that also fills `index` (index == NULL: plain trpx_encode)
  *   trpx_build_index      fills `index` from an existing stack (the walk alone)
  *   trpx_decode_indexed   = trpx_decode without the walk; the index is validated against the frame sizes
- *                           (inconsistent -> status[0] = TRPX_ERR_CORRUPT), frame_offsets is mandatory
+ *                           (inconsistent -> status[0] = TRPX_ERR_CORRUPT), frame_offsets is mandatory.
+ *                           Stacks of >= 1024 small frames that start inside a 128-byte line (pixel bytes per frame no
+ *                           multiple of 128) take the walking decoder, whose stores are line images, and only the
+ *                           header-dense frames it hands over are extracted through the index -- never slower than
+ *                           trpx_decode.  That needs a few KB for the hand-over list: one grow-only device buffer per
+ *                           calling thread, device and stream, allocated at the first such call outside stream capture
+ *                           (a capturing call that finds none takes the plain indexed route).
  */
 size_t trpx_index_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
 int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block,

@@ -126,6 +126,36 @@ DecWs dec_ws(const trpx::FrameGeom& g, size_t n_frames, size_t pixel_bytes) {
     return w;
 }
 
+// trpx_decode_indexed's hand-over list (see there): per calling thread, one buffer per (device, stream), grow-only, freed with the thread.
+struct IdxScratch {
+    struct Slot { int dev; hipStream_t st; void* p; size_t bytes; };
+    std::vector<Slot> slots;
+    ~IdxScratch() { for (auto& s : slots) if (s.p) (void)hipFree(s.p); }
+};
+void* indexed_scratch(size_t bytes, hipStream_t st) {
+    static thread_local IdxScratch t;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (auto& s : t.slots)
+        if (s.dev == dev && s.st == st) {
+            if (s.bytes >= bytes) return s.p;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+            if (hipStreamSynchronize(st) != hipSuccess) return nullptr;        // (calls that still use the smaller buffer)
+            (void)hipFree(s.p);
+            s.p = nullptr; s.bytes = 0;
+            if (hipMalloc(&s.p, bytes) != hipSuccess) { s.p = nullptr; return nullptr; }
+            s.bytes = bytes;
+            return s.p;
+        }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    t.slots.push_back({dev, st, p, bytes});
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -413,6 +443,24 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     // frames 0.30 / 0.21 -- both scale with the blocks per frame, so the frame count alone decides)
     const bool frame26 = 8 * (uint64_t)trpx_worst_case_bytes(out_dtype, n_values, block) + (1u << 17) < (1ull << 26);
     const bool per_frame = frame26 && g_decode_path != 2 && (g_decode_path == 3 || n_frames >= 1024);
+    // Frames that start inside a cache line (513 x 511 u16: most detectors): the indexed extraction's 16-byte stores are then
+    // misaligned and it LOSES to the walking decoder, whose extraction waves write line images (2000 frames: 0.33 against 0.27 ms).
+    // Such stacks take the walking decoder, and the frames it hands over -- header-dense ones, where the walk is what costs --
+    // are extracted with the caller's index instead of being walked position-parallel: never slower than trpx_decode.  The
+    // hand-over list needs a few KB of scratch, which this entry point has no argument for: one grow-only buffer per calling
+    // thread, device and stream (calls on one stream are ordered; nothing is allocated under stream capture -- a capturing call
+    // without a buffer takes the plain indexed route).
+    const bool misaligned = (g.n_values * trpx_dtype_size(out_dtype)) % 128u != 0u || (uintptr_t)pixels_out % 128u != 0u;
+    if (per_frame && misaligned && g_decode_path == 0 && trpx::parts_per_frame(g, n_frames) == 1u) {
+        void* scratch = indexed_scratch(trpx::defer_bytes(n_frames), static_cast<hipStream_t>(stream));
+        if (scratch) {
+            a.defer = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + trpx::kDeferFront);
+            a.seg_ws = scratch;                                               // (not used: no walk of the listed frames)
+            a.index_given = true;
+            HIP_TRY(trpx::launch_decode_frames(out_dtype, a, static_cast<hipStream_t>(stream)));
+            return TRPX_OK;
+        }
+    }
     HIP_TRY(trpx::launch_decode_fast(out_dtype, a, true, static_cast<hipStream_t>(stream), per_frame));
     return TRPX_OK;
 }

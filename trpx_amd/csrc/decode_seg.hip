@@ -670,8 +670,10 @@ hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st
 
 template <typename T>
 static hipError_t launch_decode_deferred_t(const DecodeArgs& a, hipStream_t st) {
-    const hipError_t e0 = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
-    if (e0 != hipSuccess) return e0;
+    if (!a.index_given) {                                                   // (trpx_decode_indexed on frames that start inside a cache line: the index is the caller's)
+        const hipError_t e0 = launch_seg_listed(a, (uint32_t)PixelTraits<T>::bits, st);
+        if (e0 != hipSuccess) return e0;
+    }
     if (seg_waves_per_frame(a.geom, a.n_frames) > 1u) {                     // large frames: their tiles, spread over the GPU
         constexpr uint32_t tb = unpack_sub_tiles<T>() * kThreads;
         const uint64_t tiles = (uint64_t)a.n_frames * ((a.geom.n_blocks + tb - 1) / tb);

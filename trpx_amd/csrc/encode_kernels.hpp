@@ -63,6 +63,7 @@ struct DecodeArgs {
     PartDesc*       parts = nullptr;           // n_frames * parts_per_frame entries
     uint32_t        parts_per_frame = 1;
     void*           part_ws = nullptr;         // part_workspace_bytes() / chain_workspace_bytes()
+    bool            index_given = false;       // a.widths / a.tile_off are the CALLER's decode index (read only): the frames the per-frame decoder lists are extracted with it, no walk
     bool            chain = false;             // large frames by the index route (decode_part.hip: one walk -> the decode index -> extraction with the widths given); parts / parts_per_frame / part_ws are that route's
 };
 uint32_t parts_per_frame(const FrameGeom& g, size_t n_frames);
