@@ -1446,7 +1446,8 @@ def test_dense_walk_last_resort_and_stress(gpu, oracle, tmp_path):
     every listed frame skips its write pass and is walked by one lane from (0, 0) -- the last resort a frame takes when its
     speculative walks do not close.  `densetiny` (-DTRPX_DENSE_SEG_BLOCKS=1): regions of a few blocks, so that link walks cross
     dozens of regions, deep records collide and the write pass's checks (end state AND block count of every region) have to
-    catch what the records got wrong -- most frames end in the serial walk, none may be wrong.  status[2] counts those frames."""
+    catch what the records got wrong -- frames that do not close end in the serial walk, none may be wrong (with 128-byte windows
+    most frames did; a region is at least one 224-byte window now, and few do).  status[2] counts those frames."""
     script = tmp_path / "t.py"
     script.write_text(f"""
 import sys
@@ -1480,7 +1481,7 @@ for dtype, n, frames in ((np.uint16, 512 * 512, 9), (np.int8, 3000, 140), (np.ui
     assert torch.equal(enc.index[: 8 * frames * ng], walked[: 8 * frames * ng]) and torch.equal(enc.index[w_off: w_off + frames * nb], walked[w_off: w_off + frames * nb]), (dtype, n, frames)
     total += int(s[2])
     hits.append(int(s[2]))
-assert total > 0 and (not want_serial or sum(1 for h in hits if h > 0) >= 3), hits     # (every LISTED frame of the serial build; which frames are listed is the per-frame decoder's call)
+assert not want_serial or (total > 0 and sum(1 for h in hits if h > 0) >= 3), hits     # (every LISTED frame of the serial build; which frames are listed is the per-frame decoder's call)
 print("OK", total)
 """)
     for name, arg in (("denseserial", "all"), ("densetiny", "some")):

@@ -161,7 +161,7 @@ struct DenseLink {
     atomicMax(&status[3], tot); atomicMax(&status[4], lnk); atomicAdd(&status[5], lnk >> 4); atomicAdd(&status[6], tot >> 4); atomicMax(&status[7], (uint32_t)(st_t1 - st_t0)); (void)st_t3; (void)st_depths; } } while (0)
 #endif
 template <uint32_t W>
-__global__ __launch_bounds__(64 * W, W >= 4 ? 2 : 3) void k_dense_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(64 * W, W >= 4 ? 1 : 2) void k_dense_frames(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                             const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
                                                             DenseRec* __restrict__ rec_all, uint64_t* __restrict__ out_all,
                                                             uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,

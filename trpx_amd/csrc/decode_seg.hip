@@ -253,12 +253,12 @@ __global__ __launch_bounds__(kWave) void k_seg_frames(const uint8_t* __restrict_
 
 // The frames k_decode_frames listed (list[0] = count, list[1 + i] = frame): one wavefront each, four to a workgroup (the
 // grid is launched for every frame of the stack and is normally empty: fewer, larger workgroups exit faster).
-__global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kWave * kSegWgWaves) void k_seg_listed(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                          const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
                                                          SegWs ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
                                                          const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
-    __shared__ uint32_t win[4][kWave * kSegRow];
-    const uint32_t i = blockIdx.x * 4u + (uint32_t)wave_id();
+    __shared__ uint32_t win[kSegWgWaves][kWave * kSegRow];
+    const uint32_t i = blockIdx.x * kSegWgWaves + (uint32_t)wave_id();
     if (i >= list[0]) return;
     const uint32_t entry = list[1 + i];                        // bit 31: a width change every third block and more -- no run to look for
     seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, entry & 0x7FFFFFFFu, win[wave_id()], status,
@@ -271,16 +271,16 @@ __global__ __launch_bounds__(kThreads) void k_seg_listed(const uint8_t* __restri
 // groups of a frame to a wavefront.  Every group is checked against its successor's state, the last one against S_f = 1 + bits/8
 // (Terse.hpp:547).  (k_walk_groups, decode_fast.hip, reads its headers straight from global memory: ~0.85 us per dependent step
 // against ~0.17 here; it stays for frames of 2^32 bits and more.)
-__global__ __launch_bounds__(kThreads) void k_seg_groups(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+__global__ __launch_bounds__(kWave * kSegWgWaves) void k_seg_groups(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                          const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
                                                          uint32_t n_frames, const uint64_t* __restrict__ states,
                                                          uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
                                                          uint32_t* __restrict__ status) {
-    __shared__ uint32_t win[4][kWave * kSegRow];
+    __shared__ uint32_t win[kSegWgWaves][kWave * kSegRow];
     constexpr uint64_t kOffMask = (1ull << 40) - 1;
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t wpf = (g.n_tiles + (uint32_t)kWave - 1u) / (uint32_t)kWave;       // wavefronts per frame
-    const uint64_t wv = (uint64_t)blockIdx.x * 4u + (uint32_t)wave_id();
+    const uint64_t wv = (uint64_t)blockIdx.x * kSegWgWaves + (uint32_t)wave_id();
     const uint64_t frame = wv / wpf;
     if (frame >= n_frames) return;
     const uint32_t k = (uint32_t)(wv % wpf) * (uint32_t)kWave + lane;                // this lane's group
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void k_seg_groups(const uint8_t* __restri
 
 hipError_t launch_seg_groups(const DecodeArgs& a, uint32_t max_w, const uint64_t* states, hipStream_t st) {
     const uint64_t waves = (uint64_t)a.n_frames * ((a.geom.n_tiles + kWave - 1) / kWave);
-    hipLaunchKernelGGL(k_seg_groups, dim3((uint32_t)((waves + 3) / 4)), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes,
+    hipLaunchKernelGGL(k_seg_groups, dim3((uint32_t)((waves + kSegWgWaves - 1) / kSegWgWaves)), dim3(kWave * kSegWgWaves), 0, st, a.terse, (uint64_t)a.terse_bytes,
                        a.frame_offsets, a.geom, max_w, a.n_frames, states, a.widths, a.tile_off, a.status);
     return hipGetLastError();
 }
@@ -663,7 +663,7 @@ hipError_t launch_seg_listed(const DecodeArgs& a, uint32_t max_w, hipStream_t st
     if (g_dense_route)
         return launch_dense_listed(a, max_w, static_cast<char*>(a.seg_ws) + seg_state_bytes(a.geom, a.n_frames), static_cast<const uint32_t*>(a.defer), st);
     const SegWs ws = seg_carve(a.seg_ws, a.n_frames, 1u);
-    hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + 3) / 4), dim3(kThreads), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
+    hipLaunchKernelGGL(k_seg_listed, dim3((a.n_frames + kSegWgWaves - 1) / kSegWgWaves), dim3(kWave * kSegWgWaves), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets,
                        a.geom, max_w, ws, a.widths, a.tile_off, static_cast<const uint32_t*>(a.defer), a.status);
     return hipGetLastError();
 }

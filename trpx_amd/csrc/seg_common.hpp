@@ -7,9 +7,15 @@
 
 namespace trpx {
 
-constexpr uint32_t kSegAdv = 768;                 // bits a window advances
-//                                                   (32 dwords are loaded per window: 127 (alignment) + 768 + 44 (peek) bits <= 1024)
-constexpr uint32_t kSegRow = 36;                  // LDS dwords per lane window (16-byte aligned rows)
+#ifndef TRPX_SEG_LOAD_DW
+#define TRPX_SEG_LOAD_DW 64
+#endif
+constexpr uint32_t kSegLoadDw = TRPX_SEG_LOAD_DW;    // dwords loaded per lane and window: 32 (128 bytes, eight lanes x 16 bytes) or 64
+constexpr uint32_t kSegPieces = kSegLoadDw / 32;     // 16-byte loads per lane and row
+constexpr uint32_t kSegAdv = 32 * kSegLoadDw - 256;  // bits a window advances: 768 (1792)
+//                                                   (127 (alignment) + advance + 44 (peek) bits <= the bits loaded, and a multiple of 128)
+constexpr uint32_t kSegRow = kSegLoadDw + 4;      // LDS dwords per lane window (16-byte aligned rows)
+constexpr uint32_t kSegWgWaves = kSegLoadDw > 32 ? 2 : 4;   // wavefronts per workgroup of the kernels that keep one window array per wavefront (64 KB of LDS per workgroup)
 constexpr uint32_t kSegSpan = 864;                // window bits a first-round guess may use (boundaries move by < kSegSpan)
 constexpr uint32_t kSegLiveMargin = 400 + kSegSpan;   // > longest block (12 + 12 * 32 bits) + boundary shift: see seg_last_live()
 
@@ -98,7 +104,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
     // for the walk against 1.68 with the whole field).
     const uint32_t wb_bits = c.max_w > 10u ? 32u - (uint32_t)__builtin_clz(c.max_w - 10u) : 0u;
     const uint32_t wb_mask = (1u << wb_bits) - 1u;
-    seg_u4 pre[8];
+    seg_u4 pre[8 * kSegPieces];
     // window t of segment s: dwords [d0, d0 + 32) with d0 = ((fa + X_s + 768 t) >> 5) & ~3
     auto fetch = [&](uint32_t t, uint64_t live) {
 #pragma unroll
@@ -106,7 +112,8 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             const uint32_t s = oct + k;
             if ((live >> s) & 1ull) {
                 const uint64_t d0 = ((c.fa + (uint64_t)Xo[k] + (uint64_t)t * kSegAdv) >> 5) & ~3ull;
-                pre[k] = seg_load16(c, d0 + 4u * piece);
+#pragma unroll
+                for (uint32_t h = 0; h < kSegPieces; ++h) pre[k * kSegPieces + h] = seg_load16(c, d0 + 4u * (piece + 8u * h));
             }
         }
     };
@@ -119,7 +126,10 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t s = oct + k;
-            if ((live >> s) & 1ull) *reinterpret_cast<seg_u4*>(&win[s * kSegRow + 4u * piece]) = pre[k];
+            if ((live >> s) & 1ull) {
+#pragma unroll
+                for (uint32_t h = 0; h < kSegPieces; ++h) *reinterpret_cast<seg_u4*>(&win[s * kSegRow + 4u * (piece + 8u * h)]) = pre[k * kSegPieces + h];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
