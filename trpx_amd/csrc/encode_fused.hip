@@ -153,10 +153,23 @@ __device__ bool lookback(const uint64_t* __restrict__ desc, int64_t idx, int64_t
 // acc[f'] with a fire-and-forget atomic as soon as it knows its size -- so a reader is ONE memory hop behind the
 // slowest contributing tile (a chain of published per-frame sizes would be two).  pref[f'] = {1 << 63 | inclusive
 // bytes} is the shortcut the frame's last tile leaves behind once it knows its own base.
+// The accumulators live on cache lines of their own -- one per frame, up to kAccLines per frame of many tiles (tile t adds to line
+// t % n_acc; the reader sums them: count and bits are both sums).  Same-line atomics are served one at a time (~10 ns): with the
+// accumulators of sixteen frames in one line, as they were until round 6, the 2048 tiles in flight of a stack of 2048 x 2048
+// frames (six frames: ONE line) queued for 20 us, every frame's base waited for the last of them, and the encoder ran at 0.29 of
+// the HBM peak on such a stack against 0.60 on 512 x 512 frames (200 x (1030 x 1065): 0.187 -> 0.125 ms, 128 x 2048^2: 0.557 -> 0.343).
 constexpr int kAccShift = 40;                                            // bits < 2^40, tiles per frame < 2^24
+#ifndef TRPX_FUSED_ACC_LINES
+#define TRPX_FUSED_ACC_LINES 2
+#endif
+constexpr uint32_t kAccLines = TRPX_FUSED_ACC_LINES;
+__host__ __device__ inline uint32_t fused_acc_lines(uint32_t tiles_per_frame) {                    // ~32 tiles and more per line
+    const uint32_t k = (tiles_per_frame + 31u) / 32u;
+    return k < 1u ? 1u : (k > kAccLines ? kAccLines : k);
+}
 constexpr uint64_t kPrefFlag = 1ull << 63;
 __device__ bool lookback_frames(const uint64_t* __restrict__ acc_w, const uint64_t* __restrict__ pref_w, int64_t frame,
-                                uint64_t tiles_per_frame, uint64_t* result) {
+                                uint64_t tiles_per_frame, uint64_t* result, uint64_t stride, uint32_t n_acc) {
     const int lane = lane_id();
     uint64_t acc = 0;
     int64_t pos = frame - 1;
@@ -171,8 +184,9 @@ __device__ bool lookback_frames(const uint64_t* __restrict__ acc_w, const uint64
         for (;;) {
             // re-read only what is still missing and still matters (see lookback)
             if (in && !(p & kPrefFlag) && !complete && ((need >> lane) & 1ull)) {
-                p = ld_desc(pref_w + my);
-                c = ld_desc(acc_w + my);
+                p = ld_desc(pref_w + my * stride);
+                c = ld_desc(acc_w + my * stride);
+                for (uint32_t k = 1; k < n_acc; ++k) c += ld_desc(acc_w + my * stride + 16u * k);   // (count and bits are both sums)
                 complete = (c >> kAccShift) == tiles_per_frame;
             }
             const uint64_t pmask = __ballot((p & kPrefFlag) != 0);
@@ -451,9 +465,11 @@ struct FusedArgs {
     uint64_t* tile_desc;           // [F * tpf]  AGG: tile bits, PREFIX: inclusive bits inside the frame
     uint64_t* tail_desc;           // [F * tpf]  exchange word of the boundary between tile-1 and tile (see the kernel's end)
     uint64_t* bnd_pos;             // [F * tpf]  output dword index of the boundary's shared dword (head side writes it)
-    uint64_t* frame_acc;           // [F]        tiles contributed << 40 | bits of the frame so far (atomic adds)
-    uint64_t* frame_pref;          // [F]        1 << 63 | inclusive bytes through this frame, once known
+    uint64_t* frame_acc;           // [F * acc_stride]  word 0 of each of the frame's n_acc lines: tiles contributed << 40 | bits so far (atomic adds)
+    uint64_t* frame_pref;          // = frame_acc + 1: word 1 of the frame's first line: 1 << 63 | inclusive bytes through this frame, once known
     uint64_t* frame_base;          // [F * 16]   1 << 63 | first byte of the frame (one 128-byte line per frame): tile 0 -> the frame's other tiles
+    uint32_t acc_stride;           // words between two frames' accumulator lines
+    uint32_t n_acc;                // accumulator lines per frame: tile t adds to line t % n_acc (word 0; line 0's word 1 is the frame's prefix)
     uint64_t* ws_tag;              // [1]        what the call before this one left behind (see launch_fused_t); checked against expect_tag if that is not 0
     uint64_t expect_tag;
     uint64_t* frame_offsets;       // [F + 1]    output
@@ -673,7 +689,7 @@ __device__ __forceinline__ void encode_fused_body(const T* __restrict__ pixels, 
     // publish this tile's bit count at once (decoupled look-back: nobody waits for our look-back)
     if (tid == 0 && !(TRPX_DIAG(a) & 1u)) {
         st_desc(a.tile_desc + tile, make_desc(t == 0 ? kStPrefix : kStAgg, tile_total));
-        __hip_atomic_fetch_add(a.frame_acc + frame, (1ull << kAccShift) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.frame_acc + (uint64_t)frame * a.acc_stride + 16u * (t % a.n_acc), (1ull << kAccShift) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (Reading the chains' first windows before the packing, to hide their round trip, was measured: 0.326 -> 0.396 ms --
     // early reads mostly miss and every extra request on the chains' hot lines delays the stores that publish them.)
@@ -747,9 +763,11 @@ __device__ __forceinline__ void encode_fused_body(const T* __restrict__ pixels, 
                 // Only the frame's FIRST tile walks the stack-wide frame chain and hands the result to its siblings
                 // through the frame's own cache line: ~70 pollers on the chain's hot lines instead of ~1000 (requests
                 // to one line are served one by one, ~10 ns each, and the publishing stores queue behind them).
-                ok = lookback_frames(a.frame_acc, a.frame_pref, (int64_t)frame, a.tiles_per_frame, &base);
+                ok = lookback_frames(a.frame_acc, a.frame_pref, (int64_t)frame, a.tiles_per_frame, &base, a.acc_stride, a.n_acc);
                 if (ok && lane == 0) st_desc(a.frame_base + (uint64_t)frame * 16, kPrefFlag | base);
             } else {
+                // (a second level -- the tiles of a frame of hundreds polling the line of their group of 8 / 32 / 128, filled by the
+                // group's first tile from the frame's -- was measured in round 6: no change at 90, 342 or 1093 tiles per frame)
                 uint64_t vb = 0;
                 SpinGuard guard;
                 for (;;) {
@@ -771,7 +789,7 @@ __device__ __forceinline__ void encode_fused_body(const T* __restrict__ pixels, 
         const uint64_t excl_bits = s_excl_bits, base_bytes = s_base_bytes;
         const uint64_t frame_size = 1 + (excl_bits + tile_total) / 8;        // valid for the frame's last tile
         if (last_tile_of_frame && tid == 0 && !aborted) {
-            st_desc(TRPX_KARG(kb, frame_pref) + frame, kPrefFlag | (base_bytes + frame_size));
+            st_desc(TRPX_KARG(kb, frame_pref) + (uint64_t)frame * TRPX_KARG(kb, acc_stride), kPrefFlag | (base_bytes + frame_size));
             TRPX_KARG(kb, frame_offsets)[frame + 1] = base_bytes + frame_size;
             if (frame == 0) TRPX_KARG(kb, frame_offsets)[0] = 0;
             if (frame + 1 == TRPX_KARG(kb, n_frames) && align_up(base_bytes + frame_size, 4) > TRPX_KARG(kb, out_capacity))
@@ -975,7 +993,8 @@ static uint32_t fused_tiles_per_frame(const FrameGeom& g) {
 
 size_t fused_workspace_bytes(const FrameGeom& g, size_t n_frames) {
     const size_t tpf = ((size_t)g.n_blocks + 2 * kThreads - 1) / (2 * kThreads);   // finest tiling (32-bit pixels)
-    return align_up(8 * (3 * n_frames * tpf + 18 * n_frames + 1), 256) + 64 * n_frames * tpf;   // + the tag + diagnostic stamps
+    // descriptor words per tile; per frame the accumulator lines and the base line; the tag; the diagnostic stamps
+    return align_up(8 * (3 * n_frames * tpf + 16 * ((size_t)kAccLines + 1) * n_frames + 1), 256) + 64 * n_frames * tpf;
 }
 
 // ---- workspaces the library knows to be clean ---------------------------------------------------------------------------------
@@ -1019,16 +1038,21 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     a.tile_desc = static_cast<uint64_t*>(ws);
     a.tail_desc = a.tile_desc + tiles;
     a.bnd_pos = a.tail_desc + tiles;
+    // per frame: n_acc accumulator lines (line 0's word 1: the prefix) and the base line -- 128 bytes each
+    a.n_acc = fused_acc_lines(a.tiles_per_frame);
+    a.acc_stride = 16u * a.n_acc;
     a.frame_acc = a.bnd_pos + tiles;
-    a.frame_pref = a.frame_acc + e.n_frames;
-    a.frame_base = a.frame_pref + e.n_frames;
+    a.frame_pref = a.frame_acc + 1;
+    a.frame_base = a.frame_acc + (size_t)a.acc_stride * e.n_frames;
     a.frame_offsets = e.frame_offsets;
     a.out32 = reinterpret_cast<uint32_t*>(e.out);
     a.status = e.status;
     a.idx_widths = e.idx_widths;
     a.idx_group_off = e.idx_group_off;
-    a.ws_tag = a.frame_base + 16 * (size_t)e.n_frames;
-    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + 18 * e.n_frames + 1), 256));
+    const size_t frame_words = 16 * ((size_t)a.n_acc + 1) * e.n_frames;
+    uint64_t* const frame_words_base = a.frame_acc;
+    a.ws_tag = frame_words_base + frame_words;
+    a.stamps = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + align_up(8 * (3 * tiles + frame_words + 1), 256));
 #ifdef TRPX_DIAGNOSTICS
     a.debug = getenv("TRPX_FUSED_DEBUG") ? (uint32_t)atoi(getenv("TRPX_FUSED_DEBUG")) : 0u;
 #else
@@ -1063,7 +1087,7 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     prof.mark(st);
     if (expect == 0)   // unknown workspace: every polled / OR-ed word, the tag and the status block (a kernel, not a memset node: see k_zero_words)
         hipLaunchKernelGGL(k_zero_words<0>, dim3(256), dim3(kThreads), 0, st, static_cast<uint64_t*>(ws),
-                           (uint64_t)(3 * tiles + 18 * e.n_frames + (capturing ? 0 : 1)), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
+                           (uint64_t)(3 * tiles + frame_words + (capturing ? 0 : 1)), reinterpret_cast<uint64_t*>(e.status), (uint64_t)4);
     prof.mark(st);
     const dim3 grid(a.tiles_per_frame, e.n_frames < kGridY ? e.n_frames : kGridY, (e.n_frames + kGridY - 1) / kGridY);
     bool mis2 = false;
@@ -1074,7 +1098,7 @@ static hipError_t launch_fused_t(const EncodeArgs& e, void* ws, hipStream_t st) 
     if (!mis2) hipLaunchKernelGGL((k_encode_fused<T>), grid, dim3(kThreads), 0, st, static_cast<const T*>(e.pixels), a);
     prof.mark(st);
     hipLaunchKernelGGL(k_stitch, dim3((uint32_t)((tiles + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                       a.tile_desc, a.tail_desc, static_cast<const uint64_t*>(a.bnd_pos), (uint64_t)tiles, a.frame_acc, (uint64_t)(18 * (size_t)e.n_frames),
+                       a.tile_desc, a.tail_desc, static_cast<const uint64_t*>(a.bnd_pos), (uint64_t)tiles, frame_words_base, (uint64_t)frame_words,
                        capturing ? static_cast<uint64_t*>(nullptr) : a.ws_tag, tag, a.out32, (uint64_t)e.out_capacity, a.status);
     prof.mark(st);
     const hipError_t err = hipGetLastError();
