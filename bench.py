@@ -32,7 +32,7 @@ N_VALUES = 512 * 512
 FRAMES_PER_GPU = 2000
 ENC_STAGES_TWOPASS = ["tile_bits", "frame_scan", "stack_scan", "zero_edges", "pack"]
 ENC_STAGES_FUSED = ["memset", "encode_fused", "stitch"]
-PROFILE_TAG = "r05"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
+PROFILE_TAG = "r06"                    # profiles/<tag>_traffic.json: PMC traffic + rocprofv3 averages of the round's final kernels
 DEC_STAGES_FRAMES = ["decode_frames", "deferred_frames"]  # one workgroup per frame (walk + extraction fused) + the frames it defers
 # frames of more than 32 K blocks (decode_part.hip, the index route): the one walk of short parts up to the part table / decode index
 # (k_chain_walk -- start states, walk and links in one launch --, k_chain_resolve, k_chain_index), then the other route's launch for listed frames
