@@ -150,8 +150,8 @@ int trpx_decode_convert(int stream_signed, int out_dtype, const uint8_t* terse, 
  *                           multiple of 128) take the walking decoder, whose stores are line images, and only the
  *                           header-dense frames it hands over are extracted through the index -- never slower than
  *                           trpx_decode.  That needs a few KB for the hand-over list: one grow-only device buffer per
- *                           calling thread, device and stream, allocated at the first such call outside stream capture
- *                           (a capturing call that finds none takes the plain indexed route).
+ *                           calling thread, device and stream, allocated at the first such call (a call that is being
+ *                           captured into a graph takes the plain indexed route and allocates nothing).
  */
 size_t trpx_index_bytes(int dtype, size_t n_values, size_t n_frames, unsigned block);
 int trpx_encode_indexed(int dtype, const void* pixels, size_t n_values, size_t n_frames, unsigned block,

@@ -128,3 +128,48 @@ def test_eager_and_replayed_encodes_alternate_on_one_workspace(gpu, oracle):
         assert out[: int(offs[-1].item())].cpu().numpy().tobytes() == want
 
     eager(); replay(); eager(); eager(); replay(); replay(); eager()
+
+
+def test_indexed_decode_of_line_straddling_frames_eager_and_captured(gpu, oracle):
+    """trpx_decode_indexed on a stack of >= 1024 small frames that start inside a cache line (31 x 33 u16 pixels: 2046 bytes per
+    frame): eagerly it takes the walking decoder + the caller's index for handed-over frames, with a hand-over list in a buffer the
+    library keeps per thread, device and stream (api.hip: indexed_scratch); a call that is being captured into a graph allocates
+    nothing and takes the plain indexed route.  Both give the pixels -- run-dominated frames and header-dense ones --, the graph
+    replays over new data, and an eager call with more frames (the buffer grows) in between does not disturb it."""
+    import torch
+    from trpx_amd import codec
+    rng = np.random.RandomState(77)
+    n, frames = 31 * 33, 1200
+    px_a = rng.poisson(3.0, (frames, n)).astype(np.uint16)                    # header-dense: handed over
+    px_b = np.minimum(rng.poisson(0.05, (frames, n)), 3).astype(np.uint16)   # long runs: kept by the walker
+    px_b[:, ::97] = 900
+    stacks = []
+    for px in (px_a, px_b):
+        d = torch.from_numpy(px.view(np.int16)).to(gpu).view(torch.uint16)
+        enc = codec.encode(d, index=True)
+        torch.cuda.synchronize()
+        enc.check()
+        assert enc.stack().cpu().numpy().tobytes() == oracle.encode_stack(px)[0].tobytes()
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16, index=enc.index)    # eager
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and (back.cpu().numpy().view(np.uint16) == px).all()
+        stacks.append((d, enc))
+    d, enc = stacks[0]
+    back = torch.empty_like(d)
+    st = torch.empty(8, dtype=torch.int32, device=gpu)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            codec.decode(enc.data, enc.frame_offsets, n, frames, np.uint16, out=back, status=st, index=enc.index)
+    for k in range(3):
+        back.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(st[0].item()) == 0 and torch.equal(back.view(torch.int16), d.view(torch.int16)), k
+        if k == 0:                                                            # an eager call with more frames: the library's buffer grows
+            big = torch.from_numpy(rng.poisson(3.0, (2 * frames, n)).astype(np.int16)).to(gpu).view(torch.uint16)
+            eb = codec.encode(big, index=True)
+            bb, sb = codec.decode(eb.stack(), eb.frame_offsets, n, 2 * frames, np.uint16, index=eb.index)
+            torch.cuda.synchronize()
+            assert int(sb[0]) == 0 and torch.equal(bb.view(torch.int16), big.view(torch.int16))

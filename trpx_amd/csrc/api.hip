@@ -136,22 +136,22 @@ void* indexed_scratch(size_t bytes, hipStream_t st) {
     static thread_local IdxScratch t;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    // never under stream capture: a graph would keep the buffer's address, and a later, larger call frees it
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     for (auto& s : t.slots)
         if (s.dev == dev && s.st == st) {
             if (s.bytes >= bytes) return s.p;
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
             if (hipStreamSynchronize(st) != hipSuccess) return nullptr;        // (calls that still use the smaller buffer)
             (void)hipFree(s.p);
             s.p = nullptr; s.bytes = 0;
-            if (hipMalloc(&s.p, bytes) != hipSuccess) { s.p = nullptr; return nullptr; }
+            if (hipMalloc(&s.p, bytes) != hipSuccess) { s.p = nullptr; (void)hipGetLastError(); return nullptr; }
             s.bytes = bytes;
             return s.p;
         }
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     t.slots.push_back({dev, st, p, bytes});
     return p;
 }
@@ -448,8 +448,8 @@ int trpx_decode_indexed(int stream_signed, int out_dtype, const uint8_t* terse, 
     // Such stacks take the walking decoder, and the frames it hands over -- header-dense ones, where the walk is what costs --
     // are extracted with the caller's index instead of being walked position-parallel: never slower than trpx_decode.  The
     // hand-over list needs a few KB of scratch, which this entry point has no argument for: one grow-only buffer per calling
-    // thread, device and stream (calls on one stream are ordered; nothing is allocated under stream capture -- a capturing call
-    // without a buffer takes the plain indexed route).
+    // thread, device and stream (calls on one stream are ordered; a call that is being captured into a graph takes the plain indexed
+    // route: a graph would keep the buffer's address, and a later, larger call frees it).
     const bool misaligned = (g.n_values * trpx_dtype_size(out_dtype)) % 128u != 0u || (uintptr_t)pixels_out % 128u != 0u;
     if (per_frame && misaligned && g_decode_path == 0 && trpx::parts_per_frame(g, n_frames) == 1u) {
         void* scratch = indexed_scratch(trpx::defer_bytes(n_frames), static_cast<hipStream_t>(stream));
