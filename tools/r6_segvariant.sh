@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 6: a variant library with decode_seg.hip compiled with extra flags.  usage: tools/r6_segvariant.sh <name> [-D...]
+# -> tools/variants/libtrpx_<name>.so (the other objects: the product build's)
+set -e
+name=$1; shift
+cd "$(dirname "$0")/../trpx_amd/csrc"
+mkdir -p ../../tools/variants
+/opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include "$@" -c decode_seg.hip -o /tmp/trpx_sv_$name.o 2>&1 | grep -E "error" || true
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/variants/libtrpx_$name.so encode.o encode_fused.o decode.o decode_fast.o decode_frame.o decode_dense.o decode_part.o shard.o bench_util.o api.o header_text.o /tmp/trpx_sv_$name.o -ldl

@@ -24,7 +24,8 @@ def flip(frames):   # block width alternates 2 / 3 / 5 every block
     return px.to(torch.int16).view(torch.uint16)
 
 from trpx_amd import workloads
-sets = [("poisson3 u16", lambda: workloads.poisson_u16(3.0, 0, 2000, n, device=dev), np.uint16),
+NF = int(os.environ.get("SEG_FRAMES", "2000"))   # (frames of the Poisson(3) set: 1000 = one walking wavefront per SIMD)
+sets = [("poisson3 u16", lambda: workloads.poisson_u16(3.0, 0, NF, n, device=dev), np.uint16),
         ("synth-v1 u16", lambda: codec.synth(np.uint16, 0, 2000, n), np.uint16),
         ("noisy u16", lambda: noisy("u16", 2000, False), np.uint16),
         ("noisy i16 (const width)", lambda: noisy("i16", 2000, True), np.int16),

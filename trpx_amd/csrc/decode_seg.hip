@@ -71,9 +71,18 @@ struct SegState {
 // ends where its own did (merged: nothing downstream changes), else it returns to its guess and waits.
 // The first open link of a wave with a true lane 0 is always taken, so the loop ends with all links closed there.
 __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restrict__ win, uint32_t k, uint32_t jl, bool first,
-                                             bool lane0_true, int max_rounds, const SegState& st, bool run_guess = true) {
+                                             bool lane0_true, int max_rounds, const SegState& st, bool run_guess = true,
+                                             uint32_t* __restrict__ ck = nullptr) {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t j = 64u * k + lane;
+    // merge stop (SegMerge, seg_common.hpp): `ck` = 64 x kSegCk words of LDS for this wavefront's checkpoints
+    const uint32_t ck_win = (c.L + 1024u + kSegAdv - 1u) / kSegAdv + 1u;
+#ifdef TRPX_SEG_NO_MERGE                                   // (A/B build: tools/r6_segvariant.sh nomerge -DTRPX_SEG_NO_MERGE)
+    const uint32_t ck_every = 0u;
+#else
+    const uint32_t ck_every = ck != nullptr && c.L + 2048u < (1u << 15) ? (ck_win + kSegCk - 1u) / kSegCk : 0u;
+#endif
+    bool has_ck = false;
     const bool walks = j < jl;                                 // lane jl and the lanes behind it own no counted blocks
     uint64_t in = seg_pack(j * c.L, 0u), out = 0ull;
     uint32_t cnt = 0u, B = j * c.L;
@@ -123,13 +132,29 @@ __device__ __forceinline__ void seg_fixpoint(const SegCtx& c, uint32_t* __restri
 #ifdef TRPX_SEG_STAMPS
             ++c.clk_rounds;
 #endif
-            seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
+            SegMerge mg{ck + lane, ck_every, has_ck, 0u, false, 0u, 0u};
+            if (ck_every) seg_walk<false, SegMerge>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad, nullptr, &mg);
+            else seg_walk<false>(c, win, 64u * k, dirty, endB, false, pos, w, n, nullptr, nullptr, bad);
             if (dirty) {
-                const uint64_t o = seg_pack(pos, w);
+                // a walk that met the lane's walk before ends where that one did, with its blocks from there on
+                const uint64_t o = mg.merged ? out : seg_pack(pos, w);
+                const uint32_t total = mg.merged ? n + (cnt - mg.n_old) : n;
+                bool keep = true;
                 if (tent) {
-                    if (o == sav_out) { out = o; cnt = n; strong = false; }          // merged: the predecessor's state is as good as mine
-                    else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; }    // back to the run guess
-                } else { out = o; cnt = n; }
+                    if (o == sav_out) { out = o; cnt = total; strong = false; }      // merged: the predecessor's state is as good as mine
+                    else { rej = in; in = sav_in; out = sav_out; cnt = sav_cnt; keep = false; }   // back to the run guess
+                } else { out = o; cnt = total; }
+                if (ck_every) {
+                    // the entries are to describe the chain the lane now holds: behind a merge the old ones, renumbered; entries the
+                    // walk did not reach, or those of a chain that was turned down, go
+                    const uint32_t shift = (n - mg.n_old) << 17;
+                    for (uint32_t i = 0; i < kSegCk; ++i) {
+                        if (!keep) ck[64u * i + lane] = 0u;
+                        else if (mg.merged) { if (i >= mg.at) { const uint32_t v = ck[64u * i + lane]; if (v) ck[64u * i + lane] = v + shift; } }
+                        else if (!((mg.wrote >> i) & 1u)) ck[64u * i + lane] = 0u;
+                    }
+                    has_ck = keep;
+                }
             }
             dirty = false; tent = false;
         }
@@ -200,7 +225,7 @@ __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse
                                                const uint64_t* __restrict__ frame_offsets, const FrameGeom& g, uint32_t max_w,
                                                const SegWs& ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
                                                uint64_t frame, uint32_t* __restrict__ win, uint32_t* __restrict__ status,
-                                               bool run_guess = true) {
+                                               bool run_guess = true, uint32_t* __restrict__ ck = nullptr) {
     const uint32_t lane = (uint32_t)lane_id();
     SegCtx c;
     if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, kWave, status)) {
@@ -215,7 +240,7 @@ __device__ __forceinline__ void seg_frame_walk(const uint8_t* __restrict__ terse
 #ifdef TRPX_SEG_STAMPS
     const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
 #endif
-    seg_fixpoint(c, win, 0u, jl, true, true, 70, st, run_guess);
+    seg_fixpoint(c, win, 0u, jl, true, true, 70, st, run_guess, ck);
     __builtin_amdgcn_s_waitcnt(0);                             // the zeroes are in L2 before the write pass stores widths
 #ifdef TRPX_SEG_STAMPS
     const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
@@ -258,11 +283,12 @@ __global__ __launch_bounds__(kWave * kSegWgWaves) void k_seg_listed(const uint8_
                                                          SegWs ws, uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
                                                          const uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     __shared__ uint32_t win[kSegWgWaves][kWave * kSegRow];
+    __shared__ uint32_t ck[kSegWgWaves][kWave * kSegCk];
     const uint32_t i = blockIdx.x * kSegWgWaves + (uint32_t)wave_id();
     if (i >= list[0]) return;
     const uint32_t entry = list[1 + i];                        // bit 31: a width change every third block and more -- no run to look for
     seg_frame_walk(terse, terse_bytes, frame_offsets, g, max_w, ws, widths, tile_off, entry & 0x7FFFFFFFu, win[wave_id()], status,
-                   (entry >> 31) == 0u);
+                   (entry >> 31) == 0u, ck[wave_id()]);
 }
 
 // ---- the index from recorded group states (row f1 for files): the write pass alone --------------------------------------------

@@ -84,6 +84,38 @@ struct SegNoHook {
     __device__ __forceinline__ bool close(uint32_t, bool, uint32_t, uint32_t&, uint32_t&, uint32_t&, bool&, uint32_t&) { return false; }
 };
 
+// Merge stop of a repeated counting walk (seg_fixpoint, decode_seg.hip).  A lane that walks its segment a second time -- from its
+// predecessor's OUT state instead of its guess -- is on a chain that merges with the one it walked before after a few dozen
+// blocks (0.7-1.5 % per block on detector data) and IS that chain from there on: OUT state and the blocks behind the merge are
+// known.  So every counting walk leaves the state in which it crosses a window boundary and its count up to there, 4 bytes in LDS
+// per boundary (column `lane` of kSegCk rows of 64), and a later walk of the same lane that crosses a boundary in the state on
+// record stops there.  Position relative to the boundary + 1 (0: no entry), width (counting walks hold widths up to 73),
+// count: segments of fewer than 2^15 bits, so that no count overflows.
+constexpr uint32_t kSegCk = 8;
+__device__ __forceinline__ uint32_t seg_ck_pack(uint32_t rel, uint32_t w, uint32_t cnt) {
+    return rel < 1023u && w < 128u && cnt < (1u << 15) ? (rel + 1u) | w << 10 | cnt << 17 : 0u;
+}
+struct SegMerge {
+    uint32_t* ck;              // this lane's column (entry i at ck[64 i])
+    uint32_t every;            // an entry per `every` window boundaries; 0: off
+    bool cmp;                  // the entries are those of the lane's walk before
+    uint32_t wrote;            // entries this walk has written
+    bool merged;               // stopped at entry `at`, where the walk before had counted n_old blocks
+    uint32_t at, n_old;
+    __device__ __forceinline__ void open(uint32_t, bool) {}
+    __device__ __forceinline__ bool close(uint32_t t, bool act0, uint32_t wend, uint32_t& pos, uint32_t& w, uint32_t& n, bool& done, uint32_t&) {
+        if (every != 0u && act0 && !done && pos >= wend) {                     // crossed the boundary behind window t, not the segment's end
+            const uint32_t b = t + 1u, q = b / every;
+            if (q * every == b && q - 1u < kSegCk) {
+                const uint32_t i = q - 1u, now = seg_ck_pack(pos - wend, w, n), old = ck[64u * i];
+                if (cmp && now != 0u && ((old ^ now) & 0x1FFFFu) == 0u) { merged = true; at = i; n_old = old >> 17; done = true; }
+                else { ck[64u * i] = now; wrote |= 1u << i; }
+            }
+        }
+        return false;
+    }
+};
+
 template <bool WRITE, class Hook = SegNoHook>
 __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__ win, uint32_t seg0, bool part, uint32_t end,
                                          bool by_count, uint32_t& pos, uint32_t& w, uint32_t& n,
@@ -169,52 +201,64 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w;
                 const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
                 const uint32_t c90 = 90u, c132 = 132u;
-                uint64_t t_ex;
+                uint64_t t_ex, t_sx;
                 uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2;
+// One counting step (copy K of the four the loop is unrolled to: a taken branch costs a walking wavefront about as much as
+// eight instructions, so the steps fall through into each other and only the fourth branches back).
+#define TRPX_SEG_COUNT_STEP(K)                                                                                                  \
+                    "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+                    "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"           /* 32 stream bits from the header on */             \
+                    "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"                    /* Terse.hpp:362 */                                 \
+                    "v_and_b32 %[t], 1, %[bits]\n\t"                                                                            \
+                    "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"                 /* block length behind a 4-bit header */            \
+                    "v_cmp_eq_u32 %[sx], 7, %[w3]\n\t"                                                                          \
+                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"                         /* header bit 1: same width (Terse.hpp:361) */      \
+                    "s_andn2_b64 %[sx], %[sx], vcc\n\t"                     /* lanes with a 6- or 12-bit header (Terse.hpp:364-370): out of line -- */ \
+                    "s_cbranch_scc1 5" #K "f\n"                             /* a block in three hundred of detector data, eleven instructions every step otherwise */ \
+                    "2" #K ":\n\t"                                                                                              \
+                    "v_cndmask_b32 %[lx], %[lx], %[ls], vcc\n\t"                                                                \
+                    "v_add_u32 %[pw], %[pw], %[lx]\n\t"                                                                         \
+                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"                                                                          \
+                    "v_and_b32 %[a], -4, %[a]\n\t"                                                                              \
+                    "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"             /* the next step's bits (lanes that leave: read and dropped) */ \
+                    "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"                                                                  \
+                    "v_add_u32 %[n], 1, %[n]\n\t"                                                                               \
+                    "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"                                                                      \
+                    "v_cmpx_lt_u32 vcc, %[pw], %[stop]\n\t"                 /* lanes leave at the end of their window share or segment */ \
+                    "s_cbranch_execz 9f\n\t"                                                                                    \
+                    "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"                     /* 32 one bits: maybe a run of empty blocks (the general step's) */ \
+                    "s_cbranch_vccnz 9f\n\t"
+#define TRPX_SEG_COUNT_WIDE(K, WB_BITS)                                                                                         \
+                    "5" #K ":\n\t"                                          /* the wide lanes' length and width */              \
+                    "v_bfe_u32 %[wa], %[bits], 4, 2\n\t"                                                                        \
+                    "v_bfe_u32 %[wb], %[bits], 6, " WB_BITS "\n\t"                                                              \
+                    "v_mad_u32_u24 %[t1], %[wa], 12, %[c90]\n\t"            /* a 6-bit header: 6 + 12 (7 + wa) */               \
+                    "v_mad_u32_u24 %[t2], %[wb], 12, %[c132]\n\t"           /* a 12-bit header: 12 + 12 (10 + wb) */            \
+                    "v_cmp_eq_u32 vcc, 3, %[wa]\n\t"                                                                            \
+                    "v_cndmask_b32 %[t1], %[t1], %[t2], vcc\n\t"                                                                \
+                    "v_add_u32 %[wa], 7, %[wa]\n\t"                                                                             \
+                    "v_add_u32 %[wb], 10, %[wb]\n\t"                                                                            \
+                    "v_cndmask_b32 %[wa], %[wa], %[wb], vcc\n\t"                                                                \
+                    "v_cndmask_b32 %[lx], %[lx], %[t1], %[sx]\n\t"                                                              \
+                    "v_cndmask_b32 %[w3], %[w3], %[wa], %[sx]\n\t"
                 asm volatile(
                     "s_mov_b64 %[ex], exec\n\t"
-                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
-                    "s_and_b64 exec, exec, vcc\n\t"
-                    "s_cbranch_scc0 9f\n\t"
+                    "v_cmpx_lt_u32 vcc, %[pw], %[stop]\n\t"
+                    "s_cbranch_execz 9f\n\t"
                     "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
                     "v_and_b32 %[a], -4, %[a]\n\t"
                     "ds_read2_b32 v[62:63], %[a] offset1:1\n"
                     "1:\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"           // 32 stream bits from the header on
-                    "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"                    // Terse.hpp:362-370
-                    "v_bfe_u32 %[wa], %[bits], 4, 2\n\t"
-                    "v_bfe_u32 %[wb], %[bits], 6, %[nb]\n\t"
-                    "v_and_b32 %[t], 1, %[bits]\n\t"
-                    "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"                 // block length behind a 4-bit header
-                    "v_mad_u32_u24 %[t1], %[wa], 12, %[c90]\n\t"            //                    a 6-bit header: 6 + 12 (7 + wa)
-                    "v_mad_u32_u24 %[t2], %[wb], 12, %[c132]\n\t"           //                    a 12-bit header: 12 + 12 (10 + wb)
-                    "v_cmp_eq_u32 vcc, 3, %[wa]\n\t"
-                    "v_cndmask_b32 %[t1], %[t1], %[t2], vcc\n\t"
-                    "v_add_u32 %[wa], 7, %[wa]\n\t"
-                    "v_add_u32 %[wb], 10, %[wb]\n\t"
-                    "v_cndmask_b32 %[wa], %[wa], %[wb], vcc\n\t"
-                    "v_cmp_eq_u32 vcc, 7, %[w3]\n\t"
-                    "v_cndmask_b32 %[lx], %[lx], %[t1], vcc\n\t"
-                    "v_cndmask_b32 %[w3], %[w3], %[wa], vcc\n\t"            // width of an explicit header
-                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"                         // header bit 1: same width (Terse.hpp:361)
-                    "v_cndmask_b32 %[lx], %[lx], %[ls], vcc\n\t"
-                    "v_add_u32 %[pw], %[pw], %[lx]\n\t"
-                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
-                    "v_and_b32 %[a], -4, %[a]\n\t"
-                    "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"             // the next step's bits (lanes that leave: read and dropped)
-                    "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"
-                    "v_add_u32 %[n], 1, %[n]\n\t"
-                    "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"
-                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
-                    "s_and_b64 exec, exec, vcc\n\t"
-                    "s_cbranch_scc0 9f\n\t"
-                    "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"
-                    "s_cbranch_vccz 1b\n"
+                    TRPX_SEG_COUNT_STEP(0) TRPX_SEG_COUNT_STEP(1) TRPX_SEG_COUNT_STEP(2) TRPX_SEG_COUNT_STEP(3)
+                    "s_branch 1b\n"
+                    TRPX_SEG_COUNT_WIDE(0, "%[nb]") "v_cmp_eq_u32 vcc, 1, %[t]\n\t" "s_branch 20b\n"
+                    TRPX_SEG_COUNT_WIDE(1, "%[nb]") "v_cmp_eq_u32 vcc, 1, %[t]\n\t" "s_branch 21b\n"
+                    TRPX_SEG_COUNT_WIDE(2, "%[nb]") "v_cmp_eq_u32 vcc, 1, %[t]\n\t" "s_branch 22b\n"
+                    TRPX_SEG_COUNT_WIDE(3, "%[nb]") "v_cmp_eq_u32 vcc, 1, %[t]\n\t" "s_branch 23b\n"
                     "9:\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[ex]\n"
-                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [ex] "=&s"(t_ex), [a] "=&v"(t_a), [bits] "=&v"(t_bits),
+                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [ex] "=&s"(t_ex), [sx] "=&s"(t_sx), [a] "=&v"(t_a), [bits] "=&v"(t_bits),
                       [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx), [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
                     : [stop] "v"(stop), [c90] "s"(c90), [c132] "s"(c132), [nb] "s"(wb_bits)
                     : "vcc", "scc", "memory", "v62", "v63");
@@ -234,81 +278,83 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 // holds when it leaves follows as bytes.
                 const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;
                 const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - wsh);
-                uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w, wmax = 0u, acc = 0u, steps = 0u;
+                uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w, wmax = w, acc = 0u;   // (wmax: the width the lane comes with, then every wide header's)
                 const uint32_t n0 = n;
                 const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
                 const uint32_t nstop = n_end - 1u;                                               // (n_end >= 1)
                 const uint32_t c90 = 90u, c132 = 132u;
-                uint64_t t_ex, t_sv;
-                uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2, t_st3;
+                uint64_t t_ex, t_sv, t_sx;
+                uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2;
+// One writing step (copy K of four, see TRPX_SEG_COUNT_STEP); STORE: the fourth copy's store of the last four widths.
+#define TRPX_SEG_WRITE_STEP(K, STORE)                                                                                           \
+                    "v_and_b32 %[t], 0xff, %[n]\n\t"                        /* block n opens a 256-block group? (7K: its header position) */ \
+                    "v_cmp_eq_u32 vcc, 0, %[t]\n\t"                                                                             \
+                    "s_cbranch_vccnz 7" #K "f\n"                                                                                \
+                    "6" #K ":\n\t"                                                                                              \
+                    "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+                    "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"                                                               \
+                    "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"                                                                        \
+                    "v_and_b32 %[t], 1, %[bits]\n\t"                                                                            \
+                    "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"                                                                     \
+                    "v_cmp_eq_u32 %[sx], 7, %[w3]\n\t"                                                                          \
+                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"                                                                             \
+                    "s_andn2_b64 %[sx], %[sx], vcc\n\t"                     /* wide headers out of line, as in the counting loop */ \
+                    "s_cbranch_scc1 5" #K "f\n"                                                                                 \
+                    "4" #K ":\n\t"                                                                                              \
+                    "v_cndmask_b32 %[lx], %[lx], %[ls], vcc\n\t"                                                                \
+                    "v_add_u32 %[pw], %[pw], %[lx]\n\t"                                                                         \
+                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"                                                                          \
+                    "v_and_b32 %[a], -4, %[a]\n\t"                                                                              \
+                    "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"                                                                 \
+                    "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"                                                                  \
+                    "v_alignbyte_b32 %[acc], %[w], %[acc], 1\n\t"           /* the last four widths, oldest in the low byte */  \
+                    "v_add_u32 %[n], 1, %[n]\n\t"                                                                               \
+                    STORE                                                                                                       \
+                    "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"                                                                      \
+                    "v_cmpx_lt_u32 vcc, %[pw], %[stop]\n\t"                                                                     \
+                    "v_cmpx_gt_u32 vcc, %[nstop], %[n]\n\t"                                                                     \
+                    "s_cbranch_execz 9f\n\t"                                                                                    \
+                    "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"                                                                         \
+                    "s_cbranch_vccnz 9f\n\t"
+#define TRPX_SEG_WRITE_TILE(K)                                                                                                  \
+                    "7" #K ":\n\t"                                                                                              \
+                    "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                         \
+                    "v_sub_u32 v60, %[pw], %[k0]\n\t"                                                                           \
+                    "v_mov_b32 v61, 0\n\t"                                                                                      \
+                    "v_lshrrev_b32 %[t], 5, %[n]\n\t"                                                                           \
+                    "v_and_b32 %[t], -8, %[t]\n\t"                                                                              \
+                    "global_store_dwordx2 %[t], v[60:61], %[tf]\n\t"                                                            \
+                    "s_mov_b64 exec, %[sv]\n\t"                                                                                 \
+                    "s_branch 6" #K "b\n"
+// (widths from 4-bit headers are at most 6: only the wide lanes' can be wider than the pixel type allows)
+#define TRPX_SEG_WRITE_WIDE(K)                                                                                                  \
+                    TRPX_SEG_COUNT_WIDE(K, "6")                                                                                 \
+                    "v_cndmask_b32 %[t2], 0, %[wa], %[sx]\n\t"                                                                  \
+                    "v_max_u32 %[wmax], %[wmax], %[t2]\n\t"                                                                     \
+                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"                                                                             \
+                    "s_branch 4" #K "b\n"
+#ifndef TRPX_SEG_NO_STORE
+#define TRPX_SEG_WIDTH_STORE "v_add_u32 %[t], -4, %[n]\n\t" "global_store_dword %[t], %[acc], %[wf]\n\t"   /* width[n - 4 .. n - 1] */
+#else
+#define TRPX_SEG_WIDTH_STORE ""                            /* (timing experiment: tools/r6_segvariant.sh nostore -DTRPX_SEG_NO_STORE) */
+#endif
                 asm volatile(
                     "s_mov_b64 %[ex], exec\n\t"
-                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
-                    "s_and_b64 exec, exec, vcc\n\t"
-                    "v_cmp_gt_u32 vcc, %[nstop], %[n]\n\t"
-                    "s_and_b64 exec, exec, vcc\n\t"
-                    "s_cbranch_scc0 9f\n\t"
+                    "v_cmpx_lt_u32 vcc, %[pw], %[stop]\n\t"
+                    "v_cmpx_gt_u32 vcc, %[nstop], %[n]\n\t"
+                    "s_cbranch_execz 9f\n\t"
                     "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
                     "v_and_b32 %[a], -4, %[a]\n\t"
                     "ds_read2_b32 v[62:63], %[a] offset1:1\n"
                     "1:\n\t"
-                    "v_and_b32 %[t], 0xff, %[n]\n\t"                        // block n opens a 256-block group: its header position
-                    "v_cmp_eq_u32 vcc, 0, %[t]\n\t"
-                    "s_cbranch_vccz 2f\n\t"
-                    "s_and_saveexec_b64 %[sv], vcc\n\t"
-                    "v_sub_u32 v60, %[pw], %[k0]\n\t"
-                    "v_mov_b32 v61, 0\n\t"
-                    "v_lshrrev_b32 %[t], 5, %[n]\n\t"
-                    "v_and_b32 %[t], -8, %[t]\n\t"
-                    "global_store_dwordx2 %[t], v[60:61], %[tf]\n\t"
-                    "s_mov_b64 exec, %[sv]\n"
-                    "2:\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"
-                    "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"
-                    "v_bfe_u32 %[wa], %[bits], 4, 2\n\t"
-                    "v_bfe_u32 %[wb], %[bits], 6, 6\n\t"
-                    "v_and_b32 %[t], 1, %[bits]\n\t"
-                    "v_mad_u32_u24 %[lx], %[w3], 12, 4\n\t"
-                    "v_mad_u32_u24 %[t1], %[wa], 12, %[c90]\n\t"
-                    "v_mad_u32_u24 %[t2], %[wb], 12, %[c132]\n\t"
-                    "v_cmp_eq_u32 vcc, 3, %[wa]\n\t"
-                    "v_cndmask_b32 %[t1], %[t1], %[t2], vcc\n\t"
-                    "v_add_u32 %[wa], 7, %[wa]\n\t"
-                    "v_add_u32 %[wb], 10, %[wb]\n\t"
-                    "v_cndmask_b32 %[wa], %[wa], %[wb], vcc\n\t"
-                    "v_cmp_eq_u32 vcc, 7, %[w3]\n\t"
-                    "v_cndmask_b32 %[lx], %[lx], %[t1], vcc\n\t"
-                    "v_cndmask_b32 %[w3], %[w3], %[wa], vcc\n\t"
-                    "v_cmp_eq_u32 vcc, 1, %[t]\n\t"
-                    "v_cndmask_b32 %[lx], %[lx], %[ls], vcc\n\t"
-                    "v_add_u32 %[pw], %[pw], %[lx]\n\t"
-                    "v_lshrrev_b32 %[a], 3, %[pw]\n\t"
-                    "v_and_b32 %[a], -4, %[a]\n\t"
-                    "ds_read2_b32 v[62:63], %[a] offset1:1\n\t"
-                    "v_cndmask_b32 %[w], %[w3], %[w], vcc\n\t"
-                    "v_lshrrev_b32 %[acc], 8, %[acc]\n\t"
-                    "v_lshl_or_b32 %[acc], %[w], 24, %[acc]\n\t"            // the last four widths, oldest in the low byte
-                    "v_add_u32 %[n], 1, %[n]\n\t"
-                    "s_add_u32 %[steps], %[steps], 1\n\t"
-                    "s_and_b32 %[st3], %[steps], 3\n\t"
-                    "s_cbranch_scc1 3f\n\t"
-                    "v_add_u32 %[t], -4, %[n]\n\t"
-                    "global_store_dword %[t], %[acc], %[wf]\n"               // width[n - 4 .. n - 1]
-                    "3:\n\t"
-                    "v_max_u32 %[wmax], %[wmax], %[w]\n\t"
-                    "v_mad_u32_u24 %[ls], %[w], 12, 1\n\t"
-                    "v_cmp_lt_u32 vcc, %[pw], %[stop]\n\t"
-                    "s_and_b64 exec, exec, vcc\n\t"
-                    "v_cmp_gt_u32 vcc, %[nstop], %[n]\n\t"
-                    "s_and_b64 exec, exec, vcc\n\t"
-                    "s_cbranch_scc0 9f\n\t"
-                    "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"
-                    "s_cbranch_vccz 1b\n"
+                    TRPX_SEG_WRITE_STEP(0, "") TRPX_SEG_WRITE_STEP(1, "") TRPX_SEG_WRITE_STEP(2, "") TRPX_SEG_WRITE_STEP(3, TRPX_SEG_WIDTH_STORE)
+                    "s_branch 1b\n"
+                    TRPX_SEG_WRITE_TILE(0) TRPX_SEG_WRITE_TILE(1) TRPX_SEG_WRITE_TILE(2) TRPX_SEG_WRITE_TILE(3)
+                    TRPX_SEG_WRITE_WIDE(0) TRPX_SEG_WRITE_WIDE(1) TRPX_SEG_WRITE_WIDE(2) TRPX_SEG_WRITE_WIDE(3)
                     "9:\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[ex]\n"
-                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [acc] "+v"(acc), [steps] "+s"(steps), [st3] "=&s"(t_st3), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv),
+                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [acc] "+v"(acc), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv), [sx] "=&s"(t_sx),
                       [a] "=&v"(t_a), [bits] "=&v"(t_bits), [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx),
                       [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
                     : [stop] "v"(stop), [k0] "v"(k0), [nstop] "v"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf), [tf] "s"(tf)
