@@ -149,8 +149,29 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
             }
         }
     };
+    // While every row's window lies inside the stream (all but a frame's last windows at the stream's end) the loads need no bounds
+    // tests and their addresses advance by a constant: window t < t_safe of row k is at rowp[k] + 56 t dwords (the 16 loads of a
+    // window with their 64-bit index arithmetic and tests were a third of a window's overhead).
+    uint32_t x_hi = X;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)x_hi, m, 64); x_hi = o > x_hi ? o : x_hi; }
+    const int64_t room = ((int64_t)c.n_dw - (int64_t)kSegLoadDw - (int64_t)((c.fa + x_hi) >> 5)) / (int64_t)(kSegAdv / 32u);
+    const uint32_t t_safe = room <= 0 ? 0u : (room > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)room);
+    const uint32_t* rowp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rowp[k] = c.s32 + (((c.fa + (uint64_t)Xo[k]) >> 5) & ~3ull) + 4u * piece;
+    auto fetch_fast = [&](uint32_t t, uint64_t live) {
+        const uint64_t adv = (uint64_t)t * (kSegAdv / 32u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((live >> (oct + k)) & 1ull) {
+#pragma unroll
+                for (uint32_t h = 0; h < kSegPieces; ++h) __builtin_memcpy(&pre[k * kSegPieces + h], rowp[k] + adv + 32u * h, 16);
+            }
+        }
+    };
     uint64_t live = __ballot(!done);
-    if (live) fetch(t_start, live);
+    if (live) { if (t_start < t_safe) fetch_fast(t_start, live); else fetch(t_start, live); }
     for (uint32_t t = t_start; live; ++t) {
 #ifdef TRPX_SEG_STAMPS
         const uint64_t clk0 = __builtin_amdgcn_s_memrealtime();
@@ -172,7 +193,7 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
         // (the hook's loads in FRONT of the next window's: loads return in order, and what is needed when this window closes must
         // not wait behind eight loads that are needed a window later)
         if constexpr (!WRITE) { if (hook) hook->open(t, act0); }
-        fetch(t + 1, live);                                   // prefetch: consumed at the top of the next iteration
+        if (t + 1u < t_safe) fetch_fast(t + 1u, live); else fetch(t + 1u, live);   // prefetch: consumed at the top of the next iteration
 #ifdef TRPX_SEG_STAMPS
         const uint64_t clk1 = __builtin_amdgcn_s_memrealtime();
         c.clk_wait[WRITE] += clk1 - clk0;
@@ -283,14 +304,16 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 const uint32_t stop = act ? (endx < wend ? endx : wend) + k0 : 0u;
                 const uint32_t nstop = n_end - 1u;                                               // (n_end >= 1)
                 const uint32_t c90 = 90u, c132 = 132u;
-                uint64_t t_ex, t_sv, t_sx;
+                // The position of a block that opens a 256-block group is latched without a branch and stored behind the loop, which takes
+                // at most 252 steps at a time: one such block per lane.
+                const uint32_t nt = (n + (uint32_t)kTileBlocks - 1u) & ~((uint32_t)kTileBlocks - 1u);
+                uint32_t grp = 0xFFFFFFFFu, left = 62u;
+                uint64_t t_ex, t_sx;
                 uint32_t t_a, t_bits, t_w3, t_wa, t_wb, t_lx, t_t, t_1, t_2;
 // One writing step (copy K of four, see TRPX_SEG_COUNT_STEP); STORE: the fourth copy's store of the last four widths.
 #define TRPX_SEG_WRITE_STEP(K, STORE)                                                                                           \
-                    "v_and_b32 %[t], 0xff, %[n]\n\t"                        /* block n opens a 256-block group? (7K: its header position) */ \
-                    "v_cmp_eq_u32 vcc, 0, %[t]\n\t"                                                                             \
-                    "s_cbranch_vccnz 7" #K "f\n"                                                                                \
-                    "6" #K ":\n\t"                                                                                              \
+                    "v_cmp_eq_u32 vcc, %[n], %[nt]\n\t"                     /* block n opens a 256-block group: its header position is kept */ \
+                    "v_cndmask_b32 %[grp], %[grp], %[pw], vcc\n\t"                                                              \
                     "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
                     "v_alignbit_b32 %[bits], v63, v62, %[pw]\n\t"                                                               \
                     "v_bfe_u32 %[w3], %[bits], 1, 3\n\t"                                                                        \
@@ -316,16 +339,6 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     "s_cbranch_execz 9f\n\t"                                                                                    \
                     "v_cmp_eq_u32 vcc, -1, %[bits]\n\t"                                                                         \
                     "s_cbranch_vccnz 9f\n\t"
-#define TRPX_SEG_WRITE_TILE(K)                                                                                                  \
-                    "7" #K ":\n\t"                                                                                              \
-                    "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                         \
-                    "v_sub_u32 v60, %[pw], %[k0]\n\t"                                                                           \
-                    "v_mov_b32 v61, 0\n\t"                                                                                      \
-                    "v_lshrrev_b32 %[t], 5, %[n]\n\t"                                                                           \
-                    "v_and_b32 %[t], -8, %[t]\n\t"                                                                              \
-                    "global_store_dwordx2 %[t], v[60:61], %[tf]\n\t"                                                            \
-                    "s_mov_b64 exec, %[sv]\n\t"                                                                                 \
-                    "s_branch 6" #K "b\n"
 // (widths from 4-bit headers are at most 6: only the wide lanes' can be wider than the pixel type allows)
 #define TRPX_SEG_WRITE_WIDE(K)                                                                                                  \
                     TRPX_SEG_COUNT_WIDE(K, "6")                                                                                 \
@@ -348,20 +361,22 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                     "ds_read2_b32 v[62:63], %[a] offset1:1\n"
                     "1:\n\t"
                     TRPX_SEG_WRITE_STEP(0, "") TRPX_SEG_WRITE_STEP(1, "") TRPX_SEG_WRITE_STEP(2, "") TRPX_SEG_WRITE_STEP(3, TRPX_SEG_WIDTH_STORE)
-                    "s_branch 1b\n"
-                    TRPX_SEG_WRITE_TILE(0) TRPX_SEG_WRITE_TILE(1) TRPX_SEG_WRITE_TILE(2) TRPX_SEG_WRITE_TILE(3)
+                    "s_sub_u32 %[left], %[left], 1\n\t"                     // (at most 252 steps at a time: one group opener per lane, see grp)
+                    "s_cbranch_scc0 1b\n\t"
+                    "s_branch 9f\n"
                     TRPX_SEG_WRITE_WIDE(0) TRPX_SEG_WRITE_WIDE(1) TRPX_SEG_WRITE_WIDE(2) TRPX_SEG_WRITE_WIDE(3)
                     "9:\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[ex]\n"
-                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [acc] "+v"(acc), [ex] "=&s"(t_ex), [sv] "=&s"(t_sv), [sx] "=&s"(t_sx),
+                    : [pw] "+v"(pw), [w] "+v"(w), [n] "+v"(n), [ls] "+v"(ls), [wmax] "+v"(wmax), [acc] "+v"(acc), [grp] "+v"(grp), [left] "+s"(left), [ex] "=&s"(t_ex), [sx] "=&s"(t_sx),
                       [a] "=&v"(t_a), [bits] "=&v"(t_bits), [w3] "=&v"(t_w3), [wa] "=&v"(t_wa), [wb] "=&v"(t_wb), [lx] "=&v"(t_lx),
                       [t] "=&v"(t_t), [t1] "=&v"(t_1), [t2] "=&v"(t_2)
-                    : [stop] "v"(stop), [k0] "v"(k0), [nstop] "v"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf), [tf] "s"(tf)
-                    : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
+                    : [stop] "v"(stop), [nt] "v"(nt), [nstop] "v"(nstop), [c90] "s"(c90), [c132] "s"(c132), [wf] "s"(wf)
+                    : "vcc", "scc", "memory", "v62", "v63");
                 if (act) {
                     const uint32_t held = (n - n0) & 3u;                                        // widths of blocks n - held .. n - 1, in acc's top bytes
                     for (uint32_t q = 0; q < held; ++q) wf[n - held + q] = (uint8_t)(acc >> (8u * (4u - held + q)));
+                    if (grp != 0xFFFFFFFFu) tf[nt / kTileBlocks] = grp - k0;                    // (nt < n: the lane has walked block nt)
                     pos = pw - k0;
                     bad = bad || wmax > c.max_w;
                     done = by_count ? n >= n_end : pos >= end;
