@@ -1495,8 +1495,9 @@ print("OK", total)
 def test_listed_large_frames_fallback_on_a_small_device(gpu, oracle, tmp_path):
     """k_seg_fallback (decode_seg.hip) synchronises its persistent grid with device-wide barriers, which needs every workgroup
     resident at once: the grid is sized by what the device holds (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, halved,
-    at most 1024).  Test build `segfbgrid`: a device that holds 24.  Header-dense frames of 1030 x 1065 and 2048 x 520 pixels
-    are listed by the large-frame routes and must come out exact through the 24-workgroup grid (status 0, no timeout)."""
+    at most 1024).  Test build `segfbgrid`: a device that holds 24 (and k_seg_wg hands every header-dense frame back after one
+    round, so that the listed frames ARE k_seg_fallback's).  Header-dense frames of 1030 x 1065 and 2048 x 520 pixels are listed
+    by the large-frame routes and must come out exact through the 24-workgroup grid (status 0, no timeout)."""
     variant = os.path.join(ROOT, "tools", "variants", "libtrpx_segfbgrid.so")
     if not os.path.exists(variant):
         pytest.skip("test variant not built (make -C trpx_amd/csrc segfbgrid)")
@@ -1518,6 +1519,78 @@ print("OK")
 """)
     r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_header_dense_large_frames_one_workgroup_each(gpu, oracle, tmp_path):
+    """Header-dense stacks of LARGE frames (decode_part.hip: chain_classify -- more than one block in six of the frames' heads
+    starts with an explicit header) are left alone by the serial part walkers, listed, and walked by k_seg_wg (decode_seg.hip):
+    one workgroup of 2 / 4 / 8 wavefronts per frame, lane per segment, links in LDS (Terse.hpp:352-389 all the same).  Product
+    build: Poisson(3) frames of the three workgroup shapes, signed and 32-bit pixels, every frame listed (status[2]), pixels
+    exact, the index built from the stream and used; a stack of run-dominated frames is NOT listed; frames 0 and last against
+    the oracle.  Test builds: `alldense` -- run-dominated synth-v1 frames are called header-dense, their links do not close in
+    twenty rounds, k_seg_wg hands them back and k_seg_fallback walks them; `segwgrounds` -- every header-dense frame is handed
+    back after one round; `noclassify` -- the serial walkers and their repairs on header-dense data (what the product does for
+    stacks whose frame heads are blank)."""
+    import torch
+    from trpx_amd import codec, _lib, workloads
+    L = _lib.lib()
+    cases = [(700 * 700, 5, np.uint16), (1030 * 1065, 6, np.uint16), (1300 * 1000, 3, np.uint16), (1030 * 1065, 3, np.int16), (1200 * 900, 3, np.int32)]
+    for n, frames, dt in cases:
+        px = workloads.poisson_u16(3.0, 0, frames, n, device=gpu)
+        if dt == np.int16: px = (px.view(torch.int16) - 3)
+        if dt == np.int32: px = px.view(torch.int16).to(torch.int32) * 37 - 90
+        assert L.trpx_decode_parts_per_frame(codec.dtype_code(dt), n, frames, 12) > 1
+        enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+        offs = enc.frame_offsets.cpu().numpy()
+        for f in (0, frames - 1):
+            want = oracle.encode_stack(px[f:f + 1].cpu().numpy())[0]
+            assert bytes(enc.data[int(offs[f]): int(offs[f + 1])].cpu().numpy()) == bytes(want), (n, f)
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt)
+        torch.cuda.synchronize()
+        s = st.cpu().numpy()
+        assert s[0] == 0 and torch.equal(back, px), (n, dt, s)
+        assert s[2] == frames, (n, dt, s)                     # every frame listed for k_seg_wg
+        idx = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, dt)
+        back2, st2 = codec.decode(enc.stack(), enc.frame_offsets, n, frames, dt, index=idx)
+        torch.cuda.synchronize()
+        assert int(st2[0]) == 0 and torch.equal(back2, px), (n, dt)
+        del px, enc, back, back2, idx
+    px = codec.synth(np.uint16, 3, 6, 1030 * 1065, device=gpu)
+    enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+    back, st = codec.decode(enc.stack(), enc.frame_offsets, 1030 * 1065, 6, np.uint16)
+    torch.cuda.synchronize()
+    assert int(st[0]) == 0 and int(st[2]) == 0 and torch.equal(back, px), st.tolist()
+    del px, enc, back
+    script = tmp_path / "t.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from trpx_amd import codec, _lib, workloads
+kind = sys.argv[1]
+for n, frames in ((1030 * 1065, 5), (1300 * 1000, 3)):
+    for data in ("poisson3", "synth"):
+        px = workloads.poisson_u16(3.0, 0, frames, n, device="cuda") if data == "poisson3" else codec.synth(np.uint16, 3, frames, n, device="cuda")
+        enc = codec.encode(px); torch.cuda.synchronize(); enc.check()
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+        torch.cuda.synchronize()
+        s = st.cpu().numpy()
+        assert s[0] == 0 and torch.equal(back, px), (kind, data, n, s)
+        if kind == "alldense": assert s[2] == frames, (kind, data, s)
+        if kind == "segwgrounds": assert s[2] == (frames if data == "poisson3" else 0), (kind, data, s)
+        if kind == "noclassify" and data == "synth": assert s[2] == 0, (kind, data, s)
+        idx = codec.build_index(enc.stack(), enc.frame_offsets, n, frames, np.uint16)
+        back2, st2 = codec.decode(enc.stack(), enc.frame_offsets, n, frames, np.uint16, index=idx)
+        torch.cuda.synchronize()
+        assert int(st2[0]) == 0 and torch.equal(back2, px), (kind, data, n)
+print("OK")
+""")
+    for name in ("alldense", "segwgrounds", "noclassify"):
+        variant = os.path.join(ROOT, "tools", "variants", f"libtrpx_{name}.so")
+        if not os.path.exists(variant):
+            pytest.skip(f"test variant not built (make -C trpx_amd/csrc {name})")
+        r = subprocess.run([os.sys.executable, str(script), name], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRPX_LIB=variant))
+        assert r.returncode == 0 and "OK" in r.stdout, (name, r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_many_large_frames_stay_whole(gpu, oracle):

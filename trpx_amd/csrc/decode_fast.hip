@@ -217,7 +217,7 @@ hipError_t launch_walk_only(const DecodeArgs& a, uint32_t max_w, bool clear_stat
     if (!lds_walk && a.seg_ws && a.chain && a.parts && a.defer) {
         // large frames: one walk of many short parts writes the index (every frame through k_chain_index: narrow = false); the
         // frames where that does not work out are listed and get theirs from the position-parallel walk
-        hipError_t e = launch_chain_zero(a, clear_status, st);
+        hipError_t e = launch_chain_zero(a, max_w, clear_status, st);
         if (e != hipSuccess) return e;
         const uint32_t* mode = nullptr;
         e = launch_build_index_chain(a, max_w, false, &mode, st);

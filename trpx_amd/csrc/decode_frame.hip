@@ -742,7 +742,11 @@ __device__ __forceinline__ void decode_frame_body(const uint8_t* __restrict__ te
         uint32_t* const defer_l = reinterpret_cast<uint32_t*>((uintptr_t)s_keep[1]);
         if (s_err == 1u) atomicMax(&status_l[0], 5u);                      // TRPX_ERR_CORRUPT
         // listed: k_seg_listed + k_decode_frames_indexed do it (bit 31: so dense that a search for runs is a waste of time)
-        if (s_err >= 2u) defer_l[1u + atomicAdd(&defer_l[0], 1u)] = (uint32_t)s_keep[2] | (s_err == 3u ? 0x80000000u : 0u);
+        if (s_err >= 2u) {
+            defer_l[1u + atomicAdd(&defer_l[0], 1u)] = (uint32_t)s_keep[2] | (s_err == 3u ? 0x80000000u : 0u);
+            // (their number, for frames of several wavefronts' worth -- k_seg_wg, decode_seg.hip; codec_common.hpp: the word at [-2])
+            if (s_err == 3u) atomicAdd(reinterpret_cast<unsigned long long*>(defer_l) - 2, 1ull);
+        }
     }
 }
 
@@ -908,7 +912,7 @@ static hipError_t launch_decode_frames_t(const DecodeArgs& a, hipStream_t st) {
     const bool chain = a.chain && a.parts && a.parts_per_frame > 1u;
     if (chain) {                                                              // (the same words and the index route's own, in one launch)
         if (!defer) return hipErrorInvalidValue;
-        const hipError_t e = launch_chain_zero(a, true, st);
+        const hipError_t e = launch_chain_zero(a, (uint32_t)PixelTraits<T>::bits, true, st);
         if (e != hipSuccess) return e;
     } else
         hipLaunchKernelGGL(k_zero_words<0>, dim3(1), dim3(kThreads), 0, st,

@@ -908,7 +908,10 @@ __global__ __launch_bounds__(kWave) void k_part_resolve(const PartState* __restr
             if (one_unit && p == 0u) d.b1 = g.n_blocks;
             pf[p] = d;
         }
-        if (!one_unit && lane == 0) list[1u + atomicAdd(&list[0], 1u)] = frame | (dense ? 0x80000000u : 0u);
+        if (!one_unit && lane == 0) {
+            list[1u + atomicAdd(&list[0], 1u)] = frame | (dense ? 0x80000000u : 0u);
+            if (dense) atomicAdd(reinterpret_cast<unsigned long long*>(list) - 2, 1ull);   // (k_seg_wg's: their number, codec_common.hpp)
+        }
 #ifdef TRPX_PART_STATS
         if (lane == 0) atomicAdd(status + 2, 1u);
 #endif
@@ -1009,7 +1012,7 @@ struct ChainFix {                              // what k_chain_repair leaves per
     uint32_t n_fix;                            // entries the repair left for its blocks [0, b_merge] (0: they did not fit)
     uint32_t pad;
 };
-struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, total; };
+struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, dense, total; };
 static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     ChainWs w;
     w.states = 0;                                                             // [states, cks): start states, walk records (with their ready / published bits) and link records, cleared in front of every call (launch_chain_zero)
@@ -1019,7 +1022,8 @@ static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     w.ents = align_up(w.cks + n_frames * P * kChainCk * sizeof(PartCk), 256);
     w.fixents = align_up(w.ents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);
     w.modes = align_up(w.fixents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);   // (a repair's entries: as many as a walk's)
-    w.total = align_up(w.modes + 4 * n_frames, 256);
+    w.dense = align_up(w.modes + 4 * n_frames, 256);                          // per frame: the classifier's vote (chain_classify; written by every call's first launch)
+    w.total = align_up(w.dense + 4 * n_frames, 256);
     return w;
 }
 size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames, size_t pixel_bytes) {
@@ -1256,16 +1260,61 @@ __device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ ters
 // part behind, which that part's wavefront publishes.  (One launch instead of a guessing and a walking one: the waits are for a
 // wavefront that needs nothing from anybody -- a neighbour's guess is 15 .. 30 us of work from its dispatch --, bounded, and a
 // wavefront that gives up reports a bad walk: the frame takes the other route.)
+// The classifier (run by the launch that clears the route's words, k_chain_zero): one wavefront per frame walks the frame's head -- 4 .. 32 Kbit, the fewer the more
+// frames the stack has (96 Kbit in all) -- from its true start state and adds its blocks and explicit headers to the stack's two counters (the
+// word in front of the listed-dense count: blocks << 32 | explicit headers).  More than one block in six starts with an explicit
+// header: a HEADER-DENSE STACK (Poisson(3) counts: one in four; one in nine for the int32 test frames, one in sixty for synth-v1)
+// -- the serial walkers of this route take a step per explicit header, 370 us for 200 x (1030 x 1065) Poisson(3) frames;
+// k_chain_walk leaves such a stack alone, k_chain_resolve lists its frames (bit 31) and k_seg_wg (decode_seg.hip) walks them lane
+// per segment.  The verdict is the stack's, not the frame's: a frame judged alone by a hundred blocks is misjudged once in a few
+// hundred, and ONE frame on the other route costs the call that route's whole latency.  (The position-parallel walk's run
+// search does not tell: random bits pass its eight-header test somewhere in most windows.)  Only the speed hangs on the verdict --
+// either walk is checked the same way --, and where the heads mislead: blank heads keep the stack on this route (round 5's time),
+// and k_seg_wg hands a frame back whose links do not close.
+// (votes[frame] = blocks << 16 | explicit headers, written by every call's first launch for every frame; the first 256 frames vote)
+__device__ __forceinline__ bool chain_stack_dense(const uint32_t* __restrict__ votes, uint32_t n_frames) {     // called by whole wavefronts
+#ifdef TRPX_CHAIN_NO_CLASSIFY                                  // (A/B build: every stack through the serial walkers, as in round 5)
+    return false;
+#elif defined(TRPX_CHAIN_ALL_DENSE)                            // (test build, make alldense: every stack to k_seg_wg)
+    return true;
+#else
+    const uint32_t lane = (uint32_t)lane_id(), n = n_frames < 256u ? n_frames : 256u;
+    uint32_t blocks = 0u, expl = 0u;
+    for (uint32_t i = lane; i < n; i += kWave) { const uint32_t v = votes[i]; blocks += v >> 16; expl += v & 0xFFFFu; }
+    blocks = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(blocks), 63);
+    expl = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(expl), 63);
+    return blocks >= 512u && 6u * expl > blocks;
+#endif
+}
+__device__ __forceinline__ void chain_classify(const uint8_t* __restrict__ terse, uint64_t terse_bytes, const uint64_t* __restrict__ frame_offsets,
+                                               uint32_t max_w, uint32_t P, uint32_t frame, uint32_t head_bits, uint32_t* __restrict__ s_chunk,
+                                               uint32_t* __restrict__ votes) {
+    const uint32_t lane = (uint32_t)lane_id();
+    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
+    PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
+    uint32_t cnt = 0u, n_exp = 0u;
+    bool bad = !f.ok || f.limit < 4u * head_bits;
+    if (!bad) {
+        uint32_t pos = 0u, w = 0u, n_ck = 0u;
+        bool dn = false;
+        part_walk<false>(f.W, s_chunk, pos, w, head_bits, f.limit, max_w, cnt, bad, dn, nullptr, 0u, n_ck, false, kPartCk, false, nullptr, 1u, false, 0u, &n_exp);
+    }
+    if (lane == 0) votes[frame] = bad ? 0u : (cnt < 0xFFFFu ? cnt : 0xFFFFu) << 16 | (n_exp < 0xFFFFu ? n_exp : 0xFFFFu);
+}
 __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                       const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
                                                       uint32_t ent_cap, PartState* states, PartWalk* walks, PartCk* cks,
                                                       uint8_t* __restrict__ ents, ChainFix* __restrict__ fixes, uint8_t* __restrict__ fixents,
-                                                      [[maybe_unused]] uint32_t* __restrict__ stamps) {
+                                                      const uint32_t* __restrict__ dense, [[maybe_unused]] uint32_t* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
     __shared__ uint32_t s_pm[kWave + 2];
     const uint32_t item = blockIdx.x;
     const uint32_t frame = item / P, p = item % P;
     const uint32_t lane = (uint32_t)lane_id();
+    if (chain_stack_dense(dense, gridDim.x / P)) {                            // a header-dense stack (chain_classify): not this walk's -- a step per explicit header;
+        if (p + 1u < P) { PartWalk r{}; r.flags = 1u; chain_walk_publish(walks + (uint64_t)frame * P + p, r); }   // k_chain_resolve lists the frames for k_seg_wg (decode_seg.hip)
+        return;
+    }
 #ifdef TRPX_CHAIN_STAMPS
     const uint64_t st_a = __builtin_amdgcn_s_memrealtime();
     uint64_t st_b = st_a, st_c = st_a;
@@ -1381,8 +1430,9 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
 // One wavefront per frame.
 __device__ __forceinline__ void chain_resolve_frame(const PartWalk* walks, const ChainFix* fixes, const FrameGeom& g, uint32_t frame,
                                                     uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
-                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ status, const uint32_t* __restrict__ dense) {
     const uint32_t lane = (uint32_t)lane_id();
+    const bool hd = chain_stack_dense(dense, gridDim.x);                      // (one wavefront per frame: k_chain_resolve)
     const PartWalk* wf = walks + (uint64_t)frame * P;
     const ChainFix* xf = fixes + (uint64_t)frame * P;
     PartDesc* __restrict__ pf = parts + (uint64_t)frame * P;
@@ -1464,7 +1514,9 @@ __device__ __forceinline__ void chain_resolve_frame(const PartWalk* walks, const
             pf[p] = d;                                                        // b1 <= b0: nothing to do for k_chain_index
         }
         if (lane == 0) {
-            list[1u + atomicAdd(&list[0], 1u)] = frame;
+            // bit 31: k_seg_wg's (their number: the word in front of the barrier counter, codec_common.hpp)
+            list[1u + atomicAdd(&list[0], 1u)] = frame | (hd ? 0x80000000u : 0u);
+            if (hd) atomicAdd(reinterpret_cast<unsigned long long*>(list) - 2, 1ull);
             atomicAdd(status + 2, 1u);                                        // status[2]: frames the index route handed to the position-parallel walk
         }
     }
@@ -1472,8 +1524,8 @@ __device__ __forceinline__ void chain_resolve_frame(const PartWalk* walks, const
 
 __global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restrict__ walks, const ChainFix* __restrict__ fixes, FrameGeom g,
                                                          uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
-                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
-    chain_resolve_frame(walks, fixes, g, blockIdx.x, P, narrow, parts, mode, list, status);
+                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status, const uint32_t* __restrict__ dense) {
+    chain_resolve_frame(walks, fixes, g, blockIdx.x, P, narrow, parts, mode, list, status, dense);
 }
 
 // Walks `nb` blocks from (pos, w_prev) -- general steps, Terse.hpp:360-372 -- and writes their widths to wf[0 .. nb) and the bit
@@ -1652,22 +1704,35 @@ __global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict
 // The words the index route needs cleared in front of every call: the status block (if asked), the deferred-frame count and the
 // stack statistics in front of it, and the route's start states, walk records and link records (ChainWs: [states, cks) -- the
 // link records too: a wavefront that skips a link writes none, and a record left by an earlier call must not be read as this
-// call's).  One launch.
+// call's).  One launch -- whose last workgroups are the classifier's (chain_classify above): one frame's head each.
 __global__ __launch_bounds__(kThreads) void k_chain_zero(uint64_t* __restrict__ p, uint64_t n, uint64_t* __restrict__ q, uint64_t m,
-                                                         uint64_t* __restrict__ r, uint64_t k) {
-    const uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kThreads;
+                                                         uint64_t* __restrict__ r, uint64_t k, uint32_t zero_blocks,
+                                                         const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                         const uint64_t* __restrict__ frame_offsets, uint32_t P, uint32_t max_w,
+                                                         uint32_t head_bits, uint32_t* __restrict__ votes) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
+    if (blockIdx.x >= zero_blocks) {                                          // the classifier's workgroups: one frame each, one wavefront
+        if (threadIdx.x < kWave) chain_classify(terse, terse_bytes, frame_offsets, max_w, P, blockIdx.x - zero_blocks, head_bits, s_chunk, votes);
+        return;
+    }
+    const uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, stride = (uint64_t)zero_blocks * kThreads;
     for (uint64_t i = i0; i < k; i += stride) r[i] = 0ull;
     for (uint64_t i = i0; i < n; i += stride) p[i] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x < m) q[threadIdx.x] = 0ull;
 }
-hipError_t launch_chain_zero(const DecodeArgs& a, bool clear_status, hipStream_t st) {
+hipError_t launch_chain_zero(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
     const uint32_t P = a.parts_per_frame;
     if (P < 4u || !a.part_ws || !a.defer) return hipErrorInvalidValue;
     const ChainWs l = chain_ws_layout(a.geom, a.n_frames, P);
     const uint64_t k = l.cks / 8;
-    hipLaunchKernelGGL(k_chain_zero, dim3((uint32_t)((k + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, st,
+    const uint32_t zero_blocks = (uint32_t)((k + 4 * kThreads - 1) / (4 * kThreads));
+    const uint32_t voters = (uint32_t)(a.n_frames < 256u ? a.n_frames : 256u);
+    const uint32_t head = 98304u / voters, head_bits = head < 4096u ? 4096u : (head > 32768u ? 32768u : head);   // (~1000 blocks and more in all: the verdict's error is 5 sigma away)
+    hipLaunchKernelGGL(k_chain_zero, dim3(zero_blocks + voters), dim3(kThreads), 0, st,
                        reinterpret_cast<uint64_t*>(a.defer) - kDeferSlots * kDeferSlotWords, (uint64_t)(kDeferSlots * kDeferSlotWords + 1),
-                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0), reinterpret_cast<uint64_t*>(a.part_ws), k);
+                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0), reinterpret_cast<uint64_t*>(a.part_ws), k, zero_blocks,
+                       a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, P, max_w, head_bits,
+                       reinterpret_cast<uint32_t*>(static_cast<char*>(a.part_ws) + l.dense));
     return hipGetLastError();
 }
 
@@ -1685,11 +1750,12 @@ hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool na
     uint8_t* ents = reinterpret_cast<uint8_t*>(ws + l.ents);
     uint8_t* fixents = reinterpret_cast<uint8_t*>(ws + l.fixents);
     uint32_t* modes = reinterpret_cast<uint32_t*>(ws + l.modes);
+    const uint32_t* dense = reinterpret_cast<const uint32_t*>(ws + l.dense);
     const uint32_t cap = chain_ent_cap(a.geom.n_blocks, P);
     hipLaunchKernelGGL(k_chain_walk, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, cap,
-                       states, walks, cks, ents, fixes, fixents, a.status);
+                       states, walks, cks, ents, fixes, fixents, dense, a.status);
     hipLaunchKernelGGL(k_chain_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartWalk*>(walks),
-                       static_cast<const ChainFix*>(fixes), a.geom, P, narrow ? 1u : 0u, a.parts, modes, a.defer, a.status);
+                       static_cast<const ChainFix*>(fixes), a.geom, P, narrow ? 1u : 0u, a.parts, modes, a.defer, a.status, dense);
     hipLaunchKernelGGL(k_chain_index, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
                        max_w, P, cap, a.parts, ents, static_cast<const ChainFix*>(fixes), static_cast<const uint8_t*>(fixents), a.widths,
                        a.tile_off, modes, a.defer, a.status);

@@ -402,6 +402,7 @@ __device__ __forceinline__ void seg_round_item(const uint8_t* __restrict__ terse
     uint64_t frame;
     bool run_guess;
     if (!seg_listed_frame(list, item / K, frame, run_guess)) return;
+    if (list && !run_guess) return;                            // (a listed header-dense frame: k_seg_wg's)
     const uint32_t k = item % K;
     SegCtx c;
     if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, K * kWave, status)) {
@@ -444,6 +445,7 @@ __device__ __forceinline__ void seg_resolve_item(const uint8_t* __restrict__ ter
     uint64_t frame;
     bool run_guess;
     if (!seg_listed_frame(list, slot, frame, run_guess)) return;
+    if (list && !run_guess) return;                            // (k_seg_wg's)
     const uint32_t lane = (uint32_t)lane_id();
     if (lane == 0) ws.fallback[frame] = 0u;
     SegCtx c;
@@ -500,6 +502,7 @@ __device__ __forceinline__ void seg_write_item(const uint8_t* __restrict__ terse
     uint64_t frame;
     bool run_guess;
     if (!seg_listed_frame(list, item / K, frame, run_guess)) return;
+    if (list && !run_guess) return;                            // (k_seg_wg's)
     const uint32_t k = item % K;
     const uint32_t lane = (uint32_t)lane_id();
     if (ws.fallback[frame]) return;                            // the serial walk does this frame
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(kWave) void k_seg_fallback(const uint8_t* __restric
     __shared__ uint32_t s_lds[kWalkChunkDw + 4 > kWave * kSegRow ? kWalkChunkDw + 4 : kWave * kSegRow];
     const uint32_t count = __hip_atomic_load(&list[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (count == 0u) return;                                                  // the normal case
+    if ((uint64_t)count == __hip_atomic_load(barrier - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // every listed frame is header-dense: k_seg_wg's
     const uint32_t items = count * K;
     uint32_t epoch = 0;
     bool ok = true;
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(kWave) void k_seg_fallback(const uint8_t* __restric
             __builtin_amdgcn_wave_barrier();
         }
         for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {         // (the flags are the resolve phase's: no barrier needed in between)
+            if ((list[1u + it] >> 31) != 0u) continue;                        // (k_seg_wg's)
             const uint64_t frame = list[1u + it] & 0x7FFFFFFFu;
             if (__hip_atomic_load(&ws.fallback[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 walk_lds_frame(terse, terse_bytes, frame_offsets, g, max_w, widths, tile_off, frame, s_lds, status);
@@ -592,6 +597,112 @@ __global__ __launch_bounds__(kWave) void k_seg_fallback(const uint8_t* __restric
     }
     if (!ok && threadIdx.x == 0) atomicMax(&status[0], 7u);                   // TRPX_ERR_TIMEOUT: a device-wide barrier gave up
 }
+
+// ---- header-dense LARGE frames: one workgroup per frame ------------------------------------------------------------------------------
+// The large-frame routes (decode_part.hip) walk a frame as a few thousand short parts, one serial walker each -- a step per run of
+// equal widths, which on header-dense data (Poisson(3) counts: seven blocks of ten start with an explicit header) is a step per
+// block: 0.12 us each, 370 us for 200 x (1030 x 1065) such frames.  The lane-per-segment walk takes 64 blocks per wavefront step of
+// 0.1 us and pays for it with speculation (rounds: ~4.8 passes), as k_seg_listed shows on 512 x 512 frames.  Here a frame the
+// routes' classifier (chain_classify) calls header-dense gets ONE workgroup of W wavefronts: 64 W segments of some hundred blocks,
+// counting rounds with the links between the wavefronts' edge lanes in LDS and a workgroup barrier per round, a prefix sum, the
+// write pass -- no launches or device-wide barriers between the rounds, and a frame ends when ITS links are closed.  Plain guesses
+// only (X_j, width 0): these frames have no runs to start in.  Every link is a lane's IN state against its predecessor's OUT state;
+// lane 0 starts in the frame's true state, so closed links make every state the frame's chain's (and the write pass checks every
+// segment's end against the next one's start, the last one against S_f, as everywhere).
+// List entries without bit 31 are k_seg_fallback's.
+#ifndef TRPX_SEG_WG_ROUNDS
+#define TRPX_SEG_WG_ROUNDS 20
+#endif
+constexpr uint32_t kSegWgRounds = TRPX_SEG_WG_ROUNDS;         // (test build segwgrounds: 1 -- every frame handed back)
+template <uint32_t W>
+__global__ __launch_bounds__(kWave * W) void k_seg_wg(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
+                                                     const uint64_t* __restrict__ frame_offsets, FrameGeom g, uint32_t max_w,
+                                                     uint8_t* __restrict__ widths, uint64_t* __restrict__ tile_off,
+                                                     uint32_t* __restrict__ list, uint64_t* __restrict__ n_dense,
+                                                     uint32_t* __restrict__ status) {
+    constexpr uint32_t G = kWave * W;
+    constexpr bool kCk = W <= 4u;                              // (merge stop: 160 KB of LDS hold eight windows or the checkpoints)
+    __shared__ uint32_t win[W][kWave * kSegRow];
+    __shared__ uint32_t ckm[kCk ? W : 1u][kCk ? kWave * kSegCk : 1u];
+    __shared__ uint64_t s_state[G];
+    __shared__ uint32_t s_tot[W];
+    if (__hip_atomic_load(n_dense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;   // the normal case
+    const uint32_t count = __hip_atomic_load(&list[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lane = (uint32_t)lane_id(), wv = (uint32_t)wave_id(), j = kWave * wv + lane;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t entry = list[1u + it];
+        if ((entry >> 31) == 0u) continue;
+        const uint64_t frame = entry & 0x7FFFFFFFu;
+        SegCtx c;
+        if (!seg_ctx(c, terse, terse_bytes, frame_offsets, frame, g, max_w, G, status)) {
+            if (threadIdx.x == 0) atomicMax(&status[0], 5u);
+            continue;
+        }
+        uint8_t* wf = widths + frame * g.n_blocks;
+        uint64_t* tf = tile_off + frame * g.n_tiles;
+        seg_zero_widths(wf, g.n_blocks, wv, W);
+        const uint32_t jl = seg_last_live(c.limit, c.L, G);
+        const bool walks = j < jl;
+        const uint32_t ck_win = (c.L + 1024u + kSegAdv - 1u) / kSegAdv + 1u;
+        const uint32_t ck_every = kCk && c.L + 2048u < (1u << 15) ? (ck_win + kSegCk - 1u) / kSegCk : 0u;
+        uint32_t* const ck = ckm[kCk ? wv : 0u];
+        uint64_t in = j == 0u ? 0ull : seg_pack(j * c.L, 0u), out = 0ull;   // the frame starts with width 0 at bit 0 (Terse.hpp:359, :505)
+        uint32_t cnt = 0u;
+        bool dirty = walks, has_ck = false, gave_up = false;
+        for (uint32_t round = 0;; ++round) {
+            if (__ballot(dirty)) {
+                uint32_t pos = (uint32_t)in, w = (uint32_t)(in >> 32), n = 0u;
+                bool bad = false;
+                SegMerge mg{ck + lane, ck_every, has_ck, 0u, false, 0u, 0u};
+                if (ck_every) seg_walk<false, SegMerge>(c, win[wv], kWave * wv, dirty, (j + 1u) * c.L, false, pos, w, n, nullptr, nullptr, bad, nullptr, &mg);
+                else seg_walk<false>(c, win[wv], kWave * wv, dirty, (j + 1u) * c.L, false, pos, w, n, nullptr, nullptr, bad);
+                if (dirty) {
+                    if (mg.merged) cnt = n + (cnt - mg.n_old);               // met the lane's walk before: its end, its blocks from there on
+                    else { out = seg_pack(pos, w); cnt = n; }
+                    if (ck_every) {                                          // (the entries describe the chain the lane now holds: see seg_fixpoint)
+                        const uint32_t shift = (n - mg.n_old) << 17;
+                        for (uint32_t i = 0; i < kSegCk; ++i) {
+                            if (mg.merged) { if (i >= mg.at) { const uint32_t v = ck[64u * i + lane]; if (v) ck[64u * i + lane] = v + shift; } }
+                            else if (!((mg.wrote >> i) & 1u)) ck[64u * i + lane] = 0u;
+                        }
+                        has_ck = true;
+                    }
+                }
+                dirty = false;
+            }
+            s_state[j] = out;
+            __syncthreads();
+            const uint64_t prev = j > 0u ? s_state[j - 1u] : in;
+            if (j > 0u && j <= jl && prev != in) { in = prev; dirty = walks; }   // an open link: the predecessor's state is the one to walk from
+            if (!__syncthreads_or(dirty ? 1 : 0)) break;
+            // Header-dense data closes its links in a handful of rounds (a false chain meets the frame's within a segment, seven
+            // times in eight).  A frame that needs more was misjudged by its head -- run-dominated data, where a plain guess may not
+            // merge for a whole segment and every round closes one link: 3.2 ms for 200 x (1030 x 1065) synth-v1 frames -- and goes
+            // back to the list as a frame with runs to look for: k_seg_fallback, launched behind this kernel.
+            if (round >= kSegWgRounds) { gave_up = true; break; }
+        }
+        if (gave_up) {
+            if (threadIdx.x == 0) {
+                list[1u + it] = entry & 0x7FFFFFFFu;
+                __hip_atomic_fetch_add(n_dense, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            continue;
+        }
+        const uint32_t cw = walks ? cnt : 0u;
+        const uint32_t inc = wave_inclusive_scan(cw);
+        if (lane == 63u) s_tot[wv] = inc;
+        s_state[j] = in;
+        __builtin_amdgcn_s_waitcnt(0);                         // the zeroes are in L2 before the write pass stores widths
+        __syncthreads();
+        uint32_t base = inc - cw;
+        for (uint32_t v = 0; v < wv; ++v) base += s_tot[v];
+        const uint64_t next_in = j + 1u < G ? s_state[j + 1u] : 0ull;
+        seg_write(c, win[wv], wv, jl, in, next_in, (j + 1u) * c.L, base, wf, tf, c.limit / 8u, status);
+        __syncthreads();                                       // (LDS: the next frame's)
+    }
+}
+uint32_t seg_wg_waves(const FrameGeom& g) { return g.n_blocks <= 51200u ? 2u : (g.n_blocks <= 102400u ? 4u : 8u); }   // ~400 blocks per lane; eight wavefronts' windows are what the LDS holds
 
 // Segments per frame: a multiple of 64.  Frames of up to 32 K blocks (512 x 512: 21 846) are one wavefront -- rounds, prefix
 // sum and write pass in one launch, which is what the per-frame decoder's deferral needs; larger frames get segments of
@@ -649,6 +760,19 @@ static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t
         // the barrier counter: the last word of the statistics slots in front of the list (codec_common.hpp), cleared with them by
         // the call's first launch and used by nothing else
         uint64_t* barrier = reinterpret_cast<uint64_t*>(a.defer) - 1;
+        // first the listed frames the route's classifier called header-dense (bit 31; their number: the word in front of the barrier's) --
+        // k_seg_wg hands back what it cannot close --, then the others
+        const uint32_t W = seg_wg_waves(a.geom);
+        const uint32_t wg_grid = (uint32_t)(a.n_frames < (W == 8u ? 256u : 512u) ? a.n_frames : (W == 8u ? 256u : 512u));
+        if (W == 2u)
+            hipLaunchKernelGGL((k_seg_wg<2>), dim3(wg_grid), dim3(kWave * 2), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                               a.widths, a.tile_off, a.defer, barrier - 1, a.status);
+        else if (W == 4u)
+            hipLaunchKernelGGL((k_seg_wg<4>), dim3(wg_grid), dim3(kWave * 4), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                               a.widths, a.tile_off, a.defer, barrier - 1, a.status);
+        else
+            hipLaunchKernelGGL((k_seg_wg<8>), dim3(wg_grid), dim3(kWave * 8), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom, max_w,
+                               a.widths, a.tile_off, a.defer, barrier - 1, a.status);
         hipLaunchKernelGGL(k_seg_fallback, dim3(seg_fallback_grid()), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
                            max_w, K, ws, a.widths, a.tile_off, list, barrier, a.status);
         return hipGetLastError();

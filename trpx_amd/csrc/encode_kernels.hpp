@@ -79,7 +79,7 @@ size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames, size_t pixel_b
 hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool narrow, const uint32_t** frame_mode, hipStream_t st);
 // ... and what has to be cleared in front of it, in one launch: the deferred-frame list's count and statistics, the route's ready
 // flags, and (clear_status) the status block
-hipError_t launch_chain_zero(const DecodeArgs& a, bool clear_status, hipStream_t st);
+hipError_t launch_chain_zero(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st);
 // decode_fast.hip: the tiled extraction of every frame with a.widths / a.tile_off given (no status clear, no profiler marks)
 hipError_t launch_unpack_tiles(int dtype, const DecodeArgs& a, hipStream_t st, const uint32_t* frame_mode = nullptr);   // frame_mode: only frames with mode 1
 

@@ -156,7 +156,11 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)x_hi, m, 64); x_hi = o > x_hi ? o : x_hi; }
     const int64_t room = ((int64_t)c.n_dw - (int64_t)kSegLoadDw - (int64_t)((c.fa + x_hi) >> 5)) / (int64_t)(kSegAdv / 32u);
+#ifdef TRPX_SEG_NO_FAST_FETCH                                  // (A/B build)
+    const uint32_t t_safe = 0u;
+#else
     const uint32_t t_safe = room <= 0 ? 0u : (room > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)room);
+#endif
     const uint32_t* rowp[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) rowp[k] = c.s32 + (((c.fa + (uint64_t)Xo[k]) >> 5) & ~3ull) + 4u * piece;
