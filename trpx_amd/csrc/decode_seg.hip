@@ -30,12 +30,17 @@
 //                 state and stores width[b] (u8, array pre-zeroed: zero widths are not stored) and the bit
 //                 offset of every 256-block group: the same decode index k_walk_lds emits, consumed by
 //                 k_unpack_tiles.  The last lane runs to n_blocks and checks S_f = 1 + bits/8 (Terse.hpp:547).
+//   kernels       k_seg_frames / k_seg_listed: a frame of up to 32 K blocks is ONE wavefront (rounds, prefix sum, write pass in one
+//                 go; a lane that walks its segment again stops where it meets its walk before, SegMerge).  k_seg_wg: a
+//                 header-dense large frame is one workgroup of 2 / 4 / 8 wavefronts, the links between them in LDS.  k_seg_round /
+//                 k_seg_resolve / k_seg_write (launch_seg_multi) and the same as one persistent launch (k_seg_fallback): large
+//                 frames with runs to start in, many wavefronts per frame, the links between them through memory.
 //
 // Stream access: each lane reads its own segment, so the bytes a wavefront needs at any moment are 64 separate
 // 128-byte pieces.  They are fetched cooperatively -- eight lanes load one segment's piece as 8 x 16 bytes, so a
 // load instruction covers eight full cache lines -- into a per-lane LDS window (position based: window t of lane j
-// holds the bits [X_j + 768 t, X_j + 768 (t+1) + lookahead)), the next window is prefetched into registers while
-// the current one is walked.  A run of zero-width blocks (header bits 1, 1 bit per block: empty detector
+// holds the bits [X_j + A t, X_j + A (t+1) + lookahead), A = kSegAdv), the next window is prefetched into registers while
+// the current one is walked (windows of 256 bytes advancing by 1792 bits since round 6).  A run of zero-width blocks (header bits 1, 1 bit per block: empty detector
 // regions) is consumed 32 blocks per step.
 #include "codec_common.hpp"
 #include "encode_kernels.hpp"
@@ -702,7 +707,12 @@ __global__ __launch_bounds__(kWave * W) void k_seg_wg(const uint8_t* __restrict_
         __syncthreads();                                       // (LDS: the next frame's)
     }
 }
-uint32_t seg_wg_waves(const FrameGeom& g) { return g.n_blocks <= 51200u ? 2u : (g.n_blocks <= 102400u ? 4u : 8u); }   // ~400 blocks per lane; eight wavefronts' windows are what the LDS holds
+#ifndef TRPX_SEG_WG_TARGET
+#define TRPX_SEG_WG_TARGET 400
+#endif
+uint32_t seg_wg_waves(const FrameGeom& g) {                   // ~TRPX_SEG_WG_TARGET blocks per lane and less; eight wavefronts' windows are what the LDS holds
+    return g.n_blocks <= 128u * TRPX_SEG_WG_TARGET ? 2u : (g.n_blocks <= 256u * TRPX_SEG_WG_TARGET ? 4u : 8u);
+}
 
 // Segments per frame: a multiple of 64.  Frames of up to 32 K blocks (512 x 512: 21 846) are one wavefront -- rounds, prefix
 // sum and write pass in one launch, which is what the per-frame decoder's deferral needs; larger frames get segments of

@@ -221,6 +221,10 @@ __device__ __forceinline__ void seg_walk(const SegCtx& c, uint32_t* __restrict__
                 // aligned, so its low five bits are the funnel shift).  Lanes leave (exec) at the end of their window share or
                 // segment; the loop ends with the last lane or when a lane reads 32 one bits, which may be a run of empty blocks:
                 // the general step below takes those 32 at a time.
+                // Round 6 (k_seg_listed on 2000 x 512^2 Poisson(3) frames 411 -> 334 us): a wavefront alone on its SIMD walks no faster
+                // than two (1000 frames take what 2000 do) -- what counts is the wavefront's own instruction stream, and in it the
+                // TAKEN branches: the headers of 6 and 12 bits (one block in three hundred) are parsed out of line, the loop is
+                // unrolled four times (one taken branch per four steps), lanes leave through v_cmpx.
                 const uint32_t endx = end < c.limit + 1u ? end : c.limit + 1u;                   // pos >= end or pos > limit: done
                 const uint32_t k0 = 8u * (uint32_t)(uintptr_t)(win + lane * kSegRow) - (w0 - wsh);   // position -> LDS bit address
                 uint32_t pw = pos + k0, ls = 1u + (uint32_t)kBlock * w;
