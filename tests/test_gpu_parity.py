@@ -1522,7 +1522,7 @@ print("OK")
 
 
 def test_header_dense_large_frames_one_workgroup_each(gpu, oracle, tmp_path):
-    """Header-dense stacks of LARGE frames (decode_part.hip: chain_classify -- more than one block in six of the frames' heads
+    """Header-dense stacks of LARGE frames (decode_part.hip: ChainVote -- more than one block in six of the voting frames' heads
     starts with an explicit header) are left alone by the serial part walkers, listed, and walked by k_seg_wg (decode_seg.hip):
     one workgroup of 2 / 4 / 8 wavefronts per frame, lane per segment, links in LDS (Terse.hpp:352-389 all the same).  Product
     build: Poisson(3) frames of the three workgroup shapes, signed and 32-bit pixels, every frame listed (status[2]), pixels

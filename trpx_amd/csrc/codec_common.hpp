@@ -156,9 +156,9 @@ __host__ __device__ inline uint64_t align_up(uint64_t x, uint64_t a) { return (x
 // The list of the frames the per-frame decoder hands over (DecodeArgs::defer): word 0 = count, words 1 .. n_frames = entries.
 // In FRONT of it (DecodeArgs::defer points at the count): kDeferSlots accumulators of the stack's statistics, one 128-byte line
 // each -- width changes << 32 | blocks, summed over the frames' first super-steps -- by which frames near the hand-over line
-// decide (decode_frame.hip); cleared with the count.  The accumulators are word 0 of every line; the last line's last two words
-// are the large-frame fallback's: [-1] k_seg_fallback's barrier counter, [-2] the number of listed frames with bit 31 set
-// (header-dense large frames: k_seg_wg's, decode_seg.hip).
+// decide (decode_frame.hip); cleared with the count.  The accumulators are word 0 of every line; the last line's last four words
+// are the large-frame routes': [-1] k_seg_fallback's barrier counter, [-2] the number of listed frames with bit 31 set
+// (header-dense large frames: k_seg_wg's, decode_seg.hip), [-3] / [-4] the index route's vote and verdict (ChainVote, decode_part.hip).
 constexpr uint32_t kDeferSlots = 64, kDeferSlotWords = 16;                 // (u64 words per slot: a cache line)
 constexpr size_t kDeferFront = 8u * kDeferSlots * kDeferSlotWords;         // bytes in front of the list
 inline size_t defer_bytes(size_t n_frames) { return kDeferFront + align_up(4 * (n_frames + 2), 256); }

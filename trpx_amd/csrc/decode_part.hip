@@ -360,8 +360,10 @@ __device__ __forceinline__ uint32_t part_try(PartWin& W, uint32_t* __restrict__ 
 // candidate, 32 K candidates), over the rest of the range: runs of that width exist nearby; (3) wider widths, one pass each,
 // only if no small width has runs here (fewer than 20 positions of a pass with 12 header bits 1: pedestals, wide data --
 // header-dense narrow data shows 20 and more and mostly skips this stage).  A cut that ends without a run starts from a plain guess.
+struct ChainVote;
+__device__ __forceinline__ bool chain_vote_look(ChainVote& v);
 __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t* __restrict__ s_pm, uint32_t X, uint32_t limit,
-                                                 uint32_t max_w, uint32_t reach) {
+                                                 uint32_t max_w, uint32_t reach, ChainVote* vote = nullptr) {   // (vote: a header-dense stack needs no guesses)
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t s_max = 1u + (uint32_t)kBlock * max_w;
     const PartState plain{X, kPartWeak};
@@ -383,6 +385,7 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
     for (uint32_t w = 1; w <= w1; ++w)
         for (uint32_t pass = 0; pass < p1; ++pass) {
             uint32_t d, n12;
+            if (vote && chain_vote_look(*vote)) return plain;
             const uint32_t q = part_try(W, s_chunk, s_pm, X + 2048u * pass, w, d, n12);
             if (q != ~0u) return PartState{q, w};
             if (d > best_d) { best_d = d; best_w = w; }
@@ -431,13 +434,61 @@ __device__ __forceinline__ PartState chain_guess(PartWin& W, uint32_t* __restric
 // blocks than its entry array holds has no entries, which the caller sees from the count.  ent[count] = the width in front of
 // the block the walk stopped at.  ck == nullptr: no checkpoints and no density stop (ck_cap: entries ck[] has room for;
 // stop_dense: the serial walker's hand-over test, the old parts route only).
+// ---- is the stack header-dense?  (the index route's vote, k_chain_walk) ----------------------------------------------------------------
+// The serial walkers of the index route take a step per explicit header: 370 us for 200 x (1030 x 1065) Poisson(3) frames (one block
+// in four starts with one), which the lane-per-segment walk of decode_seg.hip (k_seg_wg: one workgroup per frame) does in 290.  On
+// run-dominated frames it is the other way round (plain guesses inside runs do not merge: 3.2 ms for 200 synth-v1 frames).  What
+// tells the two apart is the share of explicit headers on a TRUE chain (Poisson(3): one block in four; the int32 test frames: one in
+// nine; synth-v1: one in sixty) -- the position-parallel walk's run search does not (random bits pass its eight-header test
+// somewhere in most windows) --, and part 0 of every frame starts ON the true chain.  So the wavefronts of part 0 of up to sixteen
+// frames spread over the stack first walk their share of ~1000 blocks and VOTE (blocks and explicit headers into one atomic
+// word; ~10 us), the last voter writes the verdict (more than one block in six: header-dense), and every part looks at it between
+// the passes of its guess and at its checkpoints until it reads "run-dominated": a header-dense stack's walkers stop within
+// ~20 us of the launch, k_chain_resolve lists its frames (bit 31) and k_seg_wg walks them.  The verdict is the STACK's: a frame judged alone by a hundred blocks is misjudged once in a few
+// hundred, and ONE frame on the other route costs the call that route's whole latency.  Only the speed hangs on it -- either walk is
+// checked the same way --; where the frames' heads mislead, blank heads keep the stack on this route (round 5's time) and k_seg_wg
+// hands a frame back whose links do not close.  The two words live in front of the hand-over list (codec_common.hpp: [-3] votes,
+// [-4] verdict), cleared by the call's first launch.
+constexpr uint32_t kChainVoters = 16;
+__host__ __device__ inline uint32_t chain_voters(uint32_t n_frames) { return n_frames < kChainVoters ? n_frames : kChainVoters; }
+struct ChainVote {
+    const uint64_t* words;     // words[0] = verdict (0: none yet, 1: run-dominated, 2: header-dense), words[1] = voters << 56 | blocks << 28 | explicit headers
+    bool settled;              // the verdict was "run-dominated" when last looked at: it is final, no more looks
+};
+__device__ __forceinline__ uint32_t chain_verdict(const uint64_t* words) {
+#ifdef TRPX_CHAIN_NO_CLASSIFY                                  // (test build, make noclassify: every stack through the serial walkers, as in round 5)
+    return 1u;
+#elif defined(TRPX_CHAIN_ALL_DENSE)                            // (test build, make alldense: every stack to k_seg_wg)
+    return 2u;
+#else
+    return (uint32_t)__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// A look at the verdict (at a checkpoint of a walk, between the passes of a guess); true: the stack is header-dense, stop.
+__device__ __forceinline__ bool chain_vote_look(ChainVote& v) {
+    if (v.settled) return false;
+    const uint32_t verdict = chain_verdict(v.words);
+    v.settled = verdict == 1u;
+    return verdict == 2u;
+}
+// A voter's vote: b blocks with n_exp explicit headers; the last of the stack's voters writes the verdict.
+__device__ __forceinline__ void chain_vote_cast(uint64_t* words, uint32_t voters, uint32_t b, uint32_t n_exp) {
+    if (lane_id() != 0) return;
+    const uint64_t mine = (1ull << 56) | ((uint64_t)(b < 0xFFFFFu ? b : 0xFFFFFu) << 28) | (uint64_t)(n_exp < 0xFFFFFu ? n_exp : 0xFFFFFu);
+    const uint64_t all = __hip_atomic_fetch_add(words + 1, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+    if ((uint32_t)(all >> 56) == voters) {
+        const uint64_t blocks = (all >> 28) & 0xFFFFFFFull, expl = all & 0xFFFFFFFull;
+        __hip_atomic_store(words, blocks >= 512u && 6u * expl > blocks ? 2ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <bool STORE = false>
 __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_chunk, uint32_t& pos, uint32_t& w_prev, uint32_t T,
                                           uint32_t limit, uint32_t max_w, uint32_t& count, bool& bad, bool& dense,
                                           PartCk* __restrict__ ck, uint32_t ck_every, uint32_t& n_ck, bool tolerant,
                                           uint32_t ck_cap = kPartCk, bool stop_dense = true, uint8_t* __restrict__ ent = nullptr,
                                           uint32_t ent_cap = 1u, bool abort_illegal = false, uint32_t prio_span = 0u,
-                                          uint32_t* __restrict__ exp_out = nullptr, bool ratio_stop = false) {
+                                          uint32_t* __restrict__ exp_out = nullptr, bool ratio_stop = false, ChainVote* vote = nullptr) {
     const uint32_t lane = (uint32_t)lane_id();
     uint32_t b = 0, n_exp = 0, b_ref = 0, exp_ref = 0;
     uint32_t ck_next = ck ? pos + ck_every : 0xFFFFFFFFu;
@@ -448,6 +499,7 @@ __device__ __forceinline__ void part_walk(PartWin& W, uint32_t* __restrict__ s_c
             if (n_ck < ck_cap && lane == 0) part_ck_store(ck + n_ck, PartCk{pos, w_prev, b});
             n_ck = n_ck < ck_cap ? n_ck + 1u : n_ck;
             ck_next = pos + ck_every;
+            if (vote && chain_vote_look(*vote)) { dense = true; break; }      // (k_chain_walk: a header-dense stack is k_seg_wg's)
             if (ratio_stop) {
                 // (run-dominated locales, k_chain_walk: more than 35 % explicit headers over a checkpoint interval is a chain that is
                 // not the frame's -- a false chain reads one at every other block -- even if it has not read an illegal width yet)
@@ -1012,7 +1064,7 @@ struct ChainFix {                              // what k_chain_repair leaves per
     uint32_t n_fix;                            // entries the repair left for its blocks [0, b_merge] (0: they did not fit)
     uint32_t pad;
 };
-struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, dense, total; };
+struct ChainWs { size_t states, walks, fixes, cks, ents, fixents, modes, total; };
 static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     ChainWs w;
     w.states = 0;                                                             // [states, cks): start states, walk records (with their ready / published bits) and link records, cleared in front of every call (launch_chain_zero)
@@ -1022,8 +1074,7 @@ static ChainWs chain_ws_layout(const FrameGeom& g, size_t n_frames, size_t P) {
     w.ents = align_up(w.cks + n_frames * P * kChainCk * sizeof(PartCk), 256);
     w.fixents = align_up(w.ents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);
     w.modes = align_up(w.fixents + n_frames * P * (size_t)chain_ent_cap(g.n_blocks, (uint32_t)P) + 16, 256);   // (a repair's entries: as many as a walk's)
-    w.dense = align_up(w.modes + 4 * n_frames, 256);                          // per frame: the classifier's vote (chain_classify; written by every call's first launch)
-    w.total = align_up(w.dense + 4 * n_frames, 256);
+    w.total = align_up(w.modes + 4 * n_frames, 256);
     return w;
 }
 size_t chain_workspace_bytes(const FrameGeom& g, size_t n_frames, size_t pixel_bytes) {
@@ -1260,59 +1311,25 @@ __device__ __forceinline__ void chain_link_into(const uint8_t* __restrict__ ters
 // part behind, which that part's wavefront publishes.  (One launch instead of a guessing and a walking one: the waits are for a
 // wavefront that needs nothing from anybody -- a neighbour's guess is 15 .. 30 us of work from its dispatch --, bounded, and a
 // wavefront that gives up reports a bad walk: the frame takes the other route.)
-// The classifier (run by the launch that clears the route's words, k_chain_zero): one wavefront per frame walks the frame's head -- 4 .. 32 Kbit, the fewer the more
-// frames the stack has (96 Kbit in all) -- from its true start state and adds its blocks and explicit headers to the stack's two counters (the
-// word in front of the listed-dense count: blocks << 32 | explicit headers).  More than one block in six starts with an explicit
-// header: a HEADER-DENSE STACK (Poisson(3) counts: one in four; one in nine for the int32 test frames, one in sixty for synth-v1)
-// -- the serial walkers of this route take a step per explicit header, 370 us for 200 x (1030 x 1065) Poisson(3) frames;
-// k_chain_walk leaves such a stack alone, k_chain_resolve lists its frames (bit 31) and k_seg_wg (decode_seg.hip) walks them lane
-// per segment.  The verdict is the stack's, not the frame's: a frame judged alone by a hundred blocks is misjudged once in a few
-// hundred, and ONE frame on the other route costs the call that route's whole latency.  (The position-parallel walk's run
-// search does not tell: random bits pass its eight-header test somewhere in most windows.)  Only the speed hangs on the verdict --
-// either walk is checked the same way --, and where the heads mislead: blank heads keep the stack on this route (round 5's time),
-// and k_seg_wg hands a frame back whose links do not close.
-// (votes[frame] = blocks << 16 | explicit headers, written by every call's first launch for every frame; the first 256 frames vote)
-__device__ __forceinline__ bool chain_stack_dense(const uint32_t* __restrict__ votes, uint32_t n_frames) {     // called by whole wavefronts
-#ifdef TRPX_CHAIN_NO_CLASSIFY                                  // (A/B build: every stack through the serial walkers, as in round 5)
-    return false;
-#elif defined(TRPX_CHAIN_ALL_DENSE)                            // (test build, make alldense: every stack to k_seg_wg)
-    return true;
-#else
-    const uint32_t lane = (uint32_t)lane_id(), n = n_frames < 256u ? n_frames : 256u;
-    uint32_t blocks = 0u, expl = 0u;
-    for (uint32_t i = lane; i < n; i += kWave) { const uint32_t v = votes[i]; blocks += v >> 16; expl += v & 0xFFFFu; }
-    blocks = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(blocks), 63);
-    expl = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(expl), 63);
-    return blocks >= 512u && 6u * expl > blocks;
-#endif
-}
-__device__ __forceinline__ void chain_classify(const uint8_t* __restrict__ terse, uint64_t terse_bytes, const uint64_t* __restrict__ frame_offsets,
-                                               uint32_t max_w, uint32_t P, uint32_t frame, uint32_t head_bits, uint32_t* __restrict__ s_chunk,
-                                               uint32_t* __restrict__ votes) {
-    const uint32_t lane = (uint32_t)lane_id();
-    if (lane < 4u) s_chunk[kPartChunkDw + lane] = 0u;
-    PartFrame f = part_frame(terse, terse_bytes, frame_offsets, frame, P);
-    uint32_t cnt = 0u, n_exp = 0u;
-    bool bad = !f.ok || f.limit < 4u * head_bits;
-    if (!bad) {
-        uint32_t pos = 0u, w = 0u, n_ck = 0u;
-        bool dn = false;
-        part_walk<false>(f.W, s_chunk, pos, w, head_bits, f.limit, max_w, cnt, bad, dn, nullptr, 0u, n_ck, false, kPartCk, false, nullptr, 1u, false, 0u, &n_exp);
-    }
-    if (lane == 0) votes[frame] = bad ? 0u : (cnt < 0xFFFFu ? cnt : 0xFFFFu) << 16 | (n_exp < 0xFFFFu ? n_exp : 0xFFFFu);
-}
 __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict__ terse, uint64_t terse_bytes,
                                                       const uint64_t* __restrict__ frame_offsets, uint32_t max_w, uint32_t P,
                                                       uint32_t ent_cap, PartState* states, PartWalk* walks, PartCk* cks,
                                                       uint8_t* __restrict__ ents, ChainFix* __restrict__ fixes, uint8_t* __restrict__ fixents,
-                                                      const uint32_t* __restrict__ dense, [[maybe_unused]] uint32_t* __restrict__ stamps) {
+                                                      uint64_t* __restrict__ vote_words, [[maybe_unused]] uint32_t* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
     __shared__ uint32_t s_pm[kWave + 2];
     const uint32_t item = blockIdx.x;
     const uint32_t frame = item / P, p = item % P;
     const uint32_t lane = (uint32_t)lane_id();
-    if (chain_stack_dense(dense, gridDim.x / P)) {                            // a header-dense stack (chain_classify): not this walk's -- a step per explicit header;
-        if (p + 1u < P) { PartWalk r{}; r.flags = 1u; chain_walk_publish(walks + (uint64_t)frame * P + p, r); }   // k_chain_resolve lists the frames for k_seg_wg (decode_seg.hip)
+    // (the stack's vote, see ChainVote: part 0 of up to sixteen frames votes, every part looks at the verdict at its checkpoints)
+    const uint32_t n_frames = gridDim.x / P, n_voters = chain_voters(n_frames);
+    const uint32_t my_voter = (uint32_t)(((uint64_t)frame * n_voters + n_frames - 1u) / n_frames);   // the voter whose frame this would be
+    const bool voter = p == 0u && my_voter < n_voters && (uint32_t)((uint64_t)my_voter * n_frames / n_voters) == frame;
+    ChainVote vote{vote_words, false};
+    if (chain_verdict(vote_words) == 2u) {                                    // (the test build alldense; a wavefront that starts late)
+        if (p + 1u < P) { PartWalk r0{}; r0.flags = 1u; chain_walk_publish(walks + (uint64_t)frame * P + p, r0); }
+        if (lane == 0) __hip_atomic_store(reinterpret_cast<uint64_t*>(states) + (uint64_t)frame * P + p, (uint64_t)(p * 128u) | ((uint64_t)(kPartWeak | kPartReady) << 32),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (somebody may wait for this part's start state)
         return;
     }
 #ifdef TRPX_CHAIN_STAMPS
@@ -1325,6 +1342,20 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
     PartWalk r{};
     r.flags = 1u;
     PartFrame f = chain_frame(terse, terse_bytes, frame_offsets, frame, P);
+    if (voter && chain_verdict(vote_words) == 0u) {                           // this wavefront's vote first: its share of ~1000 blocks from the frame's true start, 4 Kbit at a time
+        const uint32_t want = 1024u / n_voters < 64u ? 64u : 1024u / n_voters;
+        uint32_t vp = 0u, vw = 0u, vb = 0u, ve = 0u;
+        bool vbad = !f.ok;                                                    // (every voter votes, if with nothing: the verdict waits for the last one)
+        __builtin_amdgcn_s_setprio(3);                                        // (everybody else is looking for a start state that a header-dense stack will not need)
+        for (uint32_t T = 4096u; !vbad && vb < want && T <= 32768u && T < f.limit / 2u; T += 4096u) {   // (the walker's fast steps need their 64 candidates in front of T)
+            uint32_t c1 = 0u, e1 = 0u, n1 = 0u;
+            bool dn = false;
+            part_walk<false>(f.W, s_chunk, vp, vw, T, f.limit, max_w, c1, vbad, dn, nullptr, 0u, n1, false, kPartCk, false, nullptr, 1u, false, 0u, &e1);
+            vb += c1; ve += e1;
+        }
+        chain_vote_cast(vote_words, n_voters, vbad ? 0u : vb, vbad ? 0u : ve);
+        __builtin_amdgcn_s_setprio(0);
+    }
     PartState s{0u, 0u};                                                      // a frame starts at bit 0 with width 0 (Terse.hpp:359, :505)
     if (p != 0u) {
         if (!f.ok) s = PartState{0u, kPartWeak};
@@ -1332,7 +1363,7 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
             const uint32_t X = p * f.L;
             // the search stays inside the part's first half: a start state lies in front of the next cut
             const uint32_t reach = p + 1u < P ? f.L / 2u : (f.limit - X) / 2u;
-            s = chain_guess(f.W, s_chunk, s_pm, X, f.limit, max_w, reach);
+            s = chain_guess(f.W, s_chunk, s_pm, X, f.limit, max_w, reach, &vote);
         }
     }
     s.pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.pos);
@@ -1352,6 +1383,11 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
     st_b = __builtin_amdgcn_s_memrealtime();
 #endif
     const PartState t = chain_state_wait(states + slot + 1u);                 // (never came: t.pos = 0 -> a bad walk)
+    if (chain_verdict(vote_words) == 2u) {                                    // (the verdict came while this part looked for its start)
+        PartWalk r0{}; r0.flags = 1u;
+        if (!mute_record) chain_walk_publish(walks + slot, r0);
+        return;
+    }
     if (f.ok && t.pos > s.pos && t.pos < f.limit) {
         uint32_t pos = s.pos, w = s.w & ~kPartFlags, cnt = 0, n_ck = 0;
         bool bad = false, dense = false, stopped = false;
@@ -1387,7 +1423,12 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
             const uint32_t every = span / (kChainCk - 8u) > 4096u ? span / (kChainCk - 8u) : 4096u;
             dense = false;
             part_walk<true>(f.W, s_chunk, pos, w, t.pos, f.limit, max_w, cnt, bad, dense, cks + slot * kChainCk, every, n_ck, p != 0u,
-                            kChainCk, false, ents + slot * ent_cap, ent_cap, p != 0u, t.pos - X, &n_exp);
+                            kChainCk, false, ents + slot * ent_cap, ent_cap, p != 0u, t.pos - X, &n_exp, false, &vote);
+            if (dense && chain_verdict(vote_words) == 2u) {                   // a header-dense stack: k_seg_wg's (the record says: no walk)
+                PartWalk r0{}; r0.flags = 1u;
+                if (!mute_record) chain_walk_publish(walks + slot, r0);
+                return;
+            }
             if (!dense || bad) break;
             if (pos >= t.pos || pos - X >= patience) {
                 stopped = true;
@@ -1430,9 +1471,9 @@ __global__ __launch_bounds__(kWave) void k_chain_walk(const uint8_t* __restrict_
 // One wavefront per frame.
 __device__ __forceinline__ void chain_resolve_frame(const PartWalk* walks, const ChainFix* fixes, const FrameGeom& g, uint32_t frame,
                                                     uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
-                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ status, const uint32_t* __restrict__ dense) {
+                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
     const uint32_t lane = (uint32_t)lane_id();
-    const bool hd = chain_stack_dense(dense, gridDim.x);                      // (one wavefront per frame: k_chain_resolve)
+    const bool hd = chain_verdict(reinterpret_cast<const uint64_t*>(list) - 4) == 2u;   // (the stack's verdict, ChainVote)
     const PartWalk* wf = walks + (uint64_t)frame * P;
     const ChainFix* xf = fixes + (uint64_t)frame * P;
     PartDesc* __restrict__ pf = parts + (uint64_t)frame * P;
@@ -1524,8 +1565,8 @@ __device__ __forceinline__ void chain_resolve_frame(const PartWalk* walks, const
 
 __global__ __launch_bounds__(kWave) void k_chain_resolve(const PartWalk* __restrict__ walks, const ChainFix* __restrict__ fixes, FrameGeom g,
                                                          uint32_t P, uint32_t narrow, PartDesc* __restrict__ parts, uint32_t* __restrict__ mode,
-                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status, const uint32_t* __restrict__ dense) {
-    chain_resolve_frame(walks, fixes, g, blockIdx.x, P, narrow, parts, mode, list, status, dense);
+                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ status) {
+    chain_resolve_frame(walks, fixes, g, blockIdx.x, P, narrow, parts, mode, list, status);
 }
 
 // Walks `nb` blocks from (pos, w_prev) -- general steps, Terse.hpp:360-372 -- and writes their widths to wf[0 .. nb) and the bit
@@ -1704,35 +1745,23 @@ __global__ __launch_bounds__(kWave) void k_chain_index(const uint8_t* __restrict
 // The words the index route needs cleared in front of every call: the status block (if asked), the deferred-frame count and the
 // stack statistics in front of it, and the route's start states, walk records and link records (ChainWs: [states, cks) -- the
 // link records too: a wavefront that skips a link writes none, and a record left by an earlier call must not be read as this
-// call's).  One launch -- whose last workgroups are the classifier's (chain_classify above): one frame's head each.
+// call's).  One launch.
 __global__ __launch_bounds__(kThreads) void k_chain_zero(uint64_t* __restrict__ p, uint64_t n, uint64_t* __restrict__ q, uint64_t m,
-                                                         uint64_t* __restrict__ r, uint64_t k, uint32_t zero_blocks,
-                                                         const uint8_t* __restrict__ terse, uint64_t terse_bytes,
-                                                         const uint64_t* __restrict__ frame_offsets, uint32_t P, uint32_t max_w,
-                                                         uint32_t head_bits, uint32_t* __restrict__ votes) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[kPartChunkDw + 4];
-    if (blockIdx.x >= zero_blocks) {                                          // the classifier's workgroups: one frame each, one wavefront
-        if (threadIdx.x < kWave) chain_classify(terse, terse_bytes, frame_offsets, max_w, P, blockIdx.x - zero_blocks, head_bits, s_chunk, votes);
-        return;
-    }
-    const uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, stride = (uint64_t)zero_blocks * kThreads;
+                                                         uint64_t* __restrict__ r, uint64_t k) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kThreads;
     for (uint64_t i = i0; i < k; i += stride) r[i] = 0ull;
     for (uint64_t i = i0; i < n; i += stride) p[i] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x < m) q[threadIdx.x] = 0ull;
 }
 hipError_t launch_chain_zero(const DecodeArgs& a, uint32_t max_w, bool clear_status, hipStream_t st) {
+    (void)max_w;
     const uint32_t P = a.parts_per_frame;
     if (P < 4u || !a.part_ws || !a.defer) return hipErrorInvalidValue;
     const ChainWs l = chain_ws_layout(a.geom, a.n_frames, P);
     const uint64_t k = l.cks / 8;
-    const uint32_t zero_blocks = (uint32_t)((k + 4 * kThreads - 1) / (4 * kThreads));
-    const uint32_t voters = (uint32_t)(a.n_frames < 256u ? a.n_frames : 256u);
-    const uint32_t head = 98304u / voters, head_bits = head < 4096u ? 4096u : (head > 32768u ? 32768u : head);   // (~1000 blocks and more in all: the verdict's error is 5 sigma away)
-    hipLaunchKernelGGL(k_chain_zero, dim3(zero_blocks + voters), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(k_chain_zero, dim3((uint32_t)((k + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, st,
                        reinterpret_cast<uint64_t*>(a.defer) - kDeferSlots * kDeferSlotWords, (uint64_t)(kDeferSlots * kDeferSlotWords + 1),
-                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0), reinterpret_cast<uint64_t*>(a.part_ws), k, zero_blocks,
-                       a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, P, max_w, head_bits,
-                       reinterpret_cast<uint32_t*>(static_cast<char*>(a.part_ws) + l.dense));
+                       reinterpret_cast<uint64_t*>(a.status), (uint64_t)(clear_status ? 4 : 0), reinterpret_cast<uint64_t*>(a.part_ws), k);
     return hipGetLastError();
 }
 
@@ -1750,12 +1779,12 @@ hipError_t launch_build_index_chain(const DecodeArgs& a, uint32_t max_w, bool na
     uint8_t* ents = reinterpret_cast<uint8_t*>(ws + l.ents);
     uint8_t* fixents = reinterpret_cast<uint8_t*>(ws + l.fixents);
     uint32_t* modes = reinterpret_cast<uint32_t*>(ws + l.modes);
-    const uint32_t* dense = reinterpret_cast<const uint32_t*>(ws + l.dense);
+    uint64_t* vote_words = reinterpret_cast<uint64_t*>(a.defer) - 4;             // (ChainVote: [0] verdict, [1] votes; cleared by launch_chain_zero)
     const uint32_t cap = chain_ent_cap(a.geom.n_blocks, P);
     hipLaunchKernelGGL(k_chain_walk, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, max_w, P, cap,
-                       states, walks, cks, ents, fixes, fixents, dense, a.status);
+                       states, walks, cks, ents, fixes, fixents, vote_words, a.status);
     hipLaunchKernelGGL(k_chain_resolve, dim3(a.n_frames), dim3(kWave), 0, st, static_cast<const PartWalk*>(walks),
-                       static_cast<const ChainFix*>(fixes), a.geom, P, narrow ? 1u : 0u, a.parts, modes, a.defer, a.status, dense);
+                       static_cast<const ChainFix*>(fixes), a.geom, P, narrow ? 1u : 0u, a.parts, modes, a.defer, a.status);
     hipLaunchKernelGGL(k_chain_index, dim3(a.n_frames * P), dim3(kWave), 0, st, a.terse, (uint64_t)a.terse_bytes, a.frame_offsets, a.geom,
                        max_w, P, cap, a.parts, ents, static_cast<const ChainFix*>(fixes), static_cast<const uint8_t*>(fixents), a.widths,
                        a.tile_off, modes, a.defer, a.status);

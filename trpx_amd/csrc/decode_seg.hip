@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kWave) void k_seg_fallback(const uint8_t* __restric
 // equal widths, which on header-dense data (Poisson(3) counts: seven blocks of ten start with an explicit header) is a step per
 // block: 0.12 us each, 370 us for 200 x (1030 x 1065) such frames.  The lane-per-segment walk takes 64 blocks per wavefront step of
 // 0.1 us and pays for it with speculation (rounds: ~4.8 passes), as k_seg_listed shows on 512 x 512 frames.  Here a frame the
-// routes' classifier (chain_classify) calls header-dense gets ONE workgroup of W wavefronts: 64 W segments of some hundred blocks,
+// routes' vote (ChainVote, decode_part.hip) calls header-dense gets ONE workgroup of W wavefronts: 64 W segments of some hundred blocks,
 // counting rounds with the links between the wavefronts' edge lanes in LDS and a workgroup barrier per round, a prefix sum, the
 // write pass -- no launches or device-wide barriers between the rounds, and a frame ends when ITS links are closed.  Plain guesses
 // only (X_j, width 0): these frames have no runs to start in.  Every link is a lane's IN state against its predecessor's OUT state;
@@ -770,7 +770,7 @@ static hipError_t launch_seg_multi(const DecodeArgs& a, uint32_t max_w, uint32_t
         // the barrier counter: the last word of the statistics slots in front of the list (codec_common.hpp), cleared with them by
         // the call's first launch and used by nothing else
         uint64_t* barrier = reinterpret_cast<uint64_t*>(a.defer) - 1;
-        // first the listed frames the route's classifier called header-dense (bit 31; their number: the word in front of the barrier's) --
+        // first the listed frames of a stack the route's vote called header-dense (bit 31; their number: the word in front of the barrier's) --
         // k_seg_wg hands back what it cannot close --, then the others
         const uint32_t W = seg_wg_waves(a.geom);
         const uint32_t wg_grid = (uint32_t)(a.n_frames < (W == 8u ? 256u : 512u) ? a.n_frames : (W == 8u ? 256u : 512u));
