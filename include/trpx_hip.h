@@ -236,7 +236,9 @@ int trpx_set_encode_path(int path);
  * pixels (Terse.hpp:352-389); the setter exists for tests and A/B measurements.
  * Process-wide; also settable with the environment variable TRPX_DECODE_PATH=basic|tiles|frames|parts|dense.
  * Frames of more than 32 K blocks are cut into parts (one walk of many short parts, then extraction through the decode
- * index it yields) unless the stack holds 768 frames or more, which keep them whole on the per-frame decoder -- such a
+ * index it yields; a stack the walk's own vote finds header-dense -- more than one block in six with an explicit header --
+ * is walked one workgroup per frame, lane per segment, instead: decode_seg.hip, k_seg_wg) unless the stack holds 768 frames
+ * or more, which keep them whole on the per-frame decoder -- such a
  * stack fills the GPU by itself; TRPX_SINGLE_PART=<frames>,<blocks> moves that line for tuning runs (stacks of <frames>
  * frames and more keep frames of up to <blocks> blocks whole).
  * These three variables are the only ones the library reads; further switches exist in -DTRPX_DIAGNOSTICS builds only.
