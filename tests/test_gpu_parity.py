@@ -1880,8 +1880,9 @@ def test_large_frames_hostile_streams(gpu, oracle, dtype):
 def test_header_dense_hostile_streams(gpu, oracle, shape, frames, victim, route):
     """The same for the routes header-dense frames take -- Poisson(3) counts, a width change on one block in four: stacks of
     512 x 512 frames are handed over by the per-frame decoder to the position-parallel walk with one wavefront per frame
-    (70 frames: the hand-over is decided by the stack's statistics), frames of 1030 x 1065 fall through the part cuts to the
-    walk with several wavefronts per frame (decode_seg.hip).  Both count their blocks from states that are guesses until the
+    (70 frames: the hand-over is decided by the stack's statistics), frames of 1030 x 1065 are voted header-dense by the index
+    route's walkers (the victim's own vote may be garbage) and walked one workgroup per frame (k_seg_wg, decode_seg.hip).  Both
+    count their blocks from states that are guesses until the
     links close, in passes that do not check widths against the pixel type: a damaged frame must end in TRPX_ERR_CORRUPT or,
     where only payload bits changed, in status 0 with every other frame exact.  route 5: the listed frames through the dense walk
     (decode_dense.hip: one speculative pass, link walks, a verified write pass, the serial walk as the last resort)."""
