@@ -1560,7 +1560,21 @@ def test_header_dense_large_frames_one_workgroup_each(gpu, oracle, tmp_path):
     back, st = codec.decode(enc.stack(), enc.frame_offsets, 1030 * 1065, 6, np.uint16)
     torch.cuda.synchronize()
     assert int(st[0]) == 0 and int(st[2]) == 0 and torch.equal(back, px), st.tolist()
-    del px, enc, back
+    del enc, back
+    # mixed stacks: the verdict is the stack's -- a run-dominated frame in a header-dense stack goes to k_seg_wg with the others (and
+    # back to k_seg_fallback if its links do not close), a header-dense frame in a run-dominated stack stays with the serial walkers
+    dense = workloads.poisson_u16(3.0, 0, 6, 1030 * 1065, device=gpu)
+    for majority, odd in ((dense, px), (px, dense)):
+        mix = majority.clone()
+        mix[3] = odd[3]
+        enc = codec.encode(mix); torch.cuda.synchronize(); enc.check()
+        back, st = codec.decode(enc.stack(), enc.frame_offsets, 1030 * 1065, 6, np.uint16)
+        torch.cuda.synchronize()
+        s = st.cpu().numpy()
+        assert s[0] == 0 and torch.equal(back, mix), s
+        assert (s[2] >= 5) if majority is dense else (s[2] <= 1), s    # (the odd frame's walkers may be through before the verdict is in)
+        del mix, enc, back
+    del px, dense
     script = tmp_path / "t.py"
     script.write_text(f"""
 import sys
